@@ -1,0 +1,22 @@
+"""CPU oracle for the two-tower + ArcFace training step.
+
+TEST INFRASTRUCTURE ONLY.  This package is a plain-PyTorch fp32 CPU restatement of the
+reference's algorithm (forrestsocool/MultimodalSimilar) for the hot path named in
+BASELINE.json.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import it; the product package ``multimodalsimilar_amd`` never
+does, and fails loudly when its HIP library is missing instead of falling back to this.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * arcface_ref      - pinned: checked against outputs of the reference's own ``arcface.py``
+                       run in the build container (tests/golden/arcface_*.npz).
+  * bert_ref         - pinned: checked against the reference's ``NlpClassifier`` over HF
+                       ``BertModel`` (tests/golden/nlp_*.npz).
+  * glue (normalise+concat) - pinned through the arcface goldens composed per
+                       multimodal_classifier.py:54-56 (tests/golden/glue_*.npz).
+  * effnet_ref       - PARITY UNPINNED: the reference delegates the image tower to ``timm``,
+                       which is neither vendored in the reference nor installed here, and the
+                       reference's tests hold no vectors for it.  effnet_ref restates timm's
+                       published ``efficientnet_b0/b4`` architecture.
+  * optim_ref        - pinned against torch.optim.AdamW + transformers.get_scheduler("linear"),
+                       the exact objects the reference's train script constructs.
+"""

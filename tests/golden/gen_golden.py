@@ -1,0 +1,179 @@
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE in the build container.
+
+Run once, here (CPU):   python tests/golden/gen_golden.py
+It imports /root/reference's ``arcface`` and ``nlp_classifier`` (over HF ``BertModel`` built from a
+local config object - no downloads) and the exact optimiser/scheduler objects the reference's
+train script constructs, feeds them seeded synthetic inputs and stores inputs + outputs as .npz.
+Only the numeric vectors are committed; no reference source travels.
+cv_classifier / multimodal_classifier cannot be imported here (ModuleNotFoundError: timm), so
+the two-tower glue fixture composes the reference's ArcMarginProduct(m=0.5) with the three
+glue operations of multimodal_classifier.py:54-56 applied to stand-in tower embeddings.
+"""
+import os
+import sys
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+os.chdir(REF)
+torch.set_num_threads(4)
+
+import arcface as ref_arcface            # noqa: E402
+import nlp_classifier as ref_nlp         # noqa: E402
+from transformers import BertConfig, BertModel, get_scheduler  # noqa: E402
+
+
+def npz(name, **kw):
+    np.savez(os.path.join(OUT, name), **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                         for k, v in kw.items()})
+    print("wrote", name)
+
+
+def gen_arcface():
+    cases = [(4, 32, 10, 0.5, False), (8, 64, 50, 0.4, False), (8, 64, 50, 0.2, True), (16, 128, 1000, 0.5, False),
+             (32, 256, 777, 0.5, False)]
+    for i, (B, D, C, m, easy) in enumerate(cases):
+        g = torch.Generator().manual_seed(100 + i)
+        head = ref_arcface.ArcMarginProduct(in_feature=D, out_feature=C, s=64.0, m=m, easy_margin=easy)
+        with torch.no_grad():
+            head.weight.copy_(torch.randn(C, D, generator=g) * 0.1)
+        x = torch.randn(B, D, generator=g)
+        label = torch.randint(0, C, (B,), generator=g)
+        with torch.no_grad():
+            # force both margin branches: row 0 nearly opposite to its class row (cos <= th -> cos - mm),
+            # row 1 nearly aligned with it (cos > th -> cos(theta+m)), row 2 mildly negative (easy-margin else)
+            x[0] = -head.weight[label[0]] * 3 + 0.05 * torch.randn(D, generator=g)
+            x[1] = head.weight[label[1]] * 2 + 0.05 * torch.randn(D, generator=g)
+            x[2] = -0.3 * head.weight[label[2]] + 0.3 * torch.randn(D, generator=g)
+        x.requires_grad_(True)
+        logits = head(x, label)
+        loss = torch.nn.CrossEntropyLoss()(logits, label)
+        loss.backward()
+        logits_test = head.forward_test(x.detach())
+        npz(f"arcface_{i}.npz", x=x, weight=head.weight, label=label, s=64.0, m=m, easy=int(easy),
+            logits=logits, logits_test=logits_test, loss=loss, dx=x.grad, dw=head.weight.grad)
+    # update_m trajectory (arcface.py:35-42)
+    head = ref_arcface.ArcMarginProduct(8, 4, m=0.2)
+    traj = []
+    for d in [0.04] * 25 + [-2.0, 0.5]:
+        head.update_m(d)
+        traj.append([head.m, head.cos_m, head.sin_m, head.th, head.mm])
+    npz("arcface_update_m.npz", deltas=np.array([0.04] * 25 + [-2.0, 0.5]), traj=np.array(traj))
+
+
+def gen_nlp():
+    cfgs = {
+        "tiny": dict(vocab_size=128, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                     intermediate_size=512, max_position_embeddings=64, B=4, S=32, C=40, store_weights=True),
+        "mid": dict(vocab_size=256, hidden_size=256, num_hidden_layers=2, num_attention_heads=4,
+                    intermediate_size=1024, max_position_embeddings=128, B=2, S=128, C=300, store_weights=False),
+    }
+    sys.path.insert(0, os.path.abspath(os.path.join(OUT, "..", "..")))
+    from oracle import bert_ref
+    for name, c in cfgs.items():
+        torch.manual_seed(7)
+        conf = BertConfig(vocab_size=c["vocab_size"], hidden_size=c["hidden_size"],
+                          num_hidden_layers=c["num_hidden_layers"], num_attention_heads=c["num_attention_heads"],
+                          intermediate_size=c["intermediate_size"], max_position_embeddings=c["max_position_embeddings"],
+                          hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        conf._attn_implementation = "eager"
+        ptm = BertModel(conf)
+        shape = bert_ref.BertShape(vocab_size=c["vocab_size"], hidden_size=c["hidden_size"],
+                                   num_hidden_layers=c["num_hidden_layers"], num_attention_heads=c["num_attention_heads"],
+                                   intermediate_size=c["intermediate_size"],
+                                   max_position_embeddings=c["max_position_embeddings"])
+        sd0 = bert_ref.init_state(shape, seed=11)
+        # non-trivial LN / bias values so every term of the backward is exercised
+        g = torch.Generator().manual_seed(12)
+        for k in sd0:
+            if k.endswith("LayerNorm.weight"):
+                sd0[k] = 1.0 + 0.1 * torch.randn(sd0[k].shape, generator=g)
+            elif k.endswith(".bias"):
+                sd0[k] = 0.05 * torch.randn(sd0[k].shape, generator=g)
+        missing = ptm.load_state_dict(sd0, strict=False)
+        assert not missing.missing_keys or all("position_ids" in k for k in missing.missing_keys), missing
+        model = ref_nlp.NlpClassifier(ptm, num_labels=c["C"])
+        model.train()   # dropout p=0 in config; NlpClassifier's own nn.Dropout is never applied (E6)
+        with torch.no_grad():
+            model.classifier.weight.copy_(torch.randn(c["C"], c["hidden_size"], generator=g) * 0.05)
+        B, S = c["B"], c["S"]
+        ids = torch.randint(0, c["vocab_size"], (B, S), generator=g)
+        tt = torch.randint(0, 2, (B, S), generator=g)
+        lens = torch.randint(S // 4, S + 1, (B,), generator=g)
+        lens[0] = S
+        mask = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).long()
+        label = torch.randint(0, c["C"], (B,), generator=g)
+        emb = model.predict_emb(ids, tt, None, mask)
+        logits = model(ids, tt, None, mask, label)
+        loss = torch.nn.CrossEntropyLoss()(logits, label)
+        loss.backward()
+        logits_test = model(ids, tt, None, mask, label, is_test=True)
+        out = dict(input_ids=ids, token_type_ids=tt, attention_mask=mask, label=label, pooled=emb, logits=logits,
+                   logits_test=logits_test, loss=loss, head_weight=model.classifier.weight,
+                   head_grad=model.classifier.weight.grad, seed_state=11, seed_perturb=12)
+        grads = {n: p.grad for n, p in ptm.named_parameters() if p.grad is not None}
+        if c["store_weights"]:
+            for k, v in sd0.items():
+                out["w::" + k] = v
+            for k, v in grads.items():
+                out["g::" + k] = v
+        else:
+            for k, v in grads.items():
+                out["gnorm::" + k] = v.norm()
+            out["g::pooler.dense.weight"] = grads["pooler.dense.weight"]
+            out["g::encoder.layer.0.attention.self.query.bias"] = grads["encoder.layer.0.attention.self.query.bias"]
+        npz(f"nlp_{name}.npz", **out)
+
+
+def gen_glue():
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    B, Di, Dt, C = 8, 48, 32, 25
+    img = (torch.randn(B, Di, generator=g) * 3).requires_grad_(True)
+    txt = torch.tanh(torch.randn(B, Dt, generator=g)).requires_grad_(True)
+    head = ref_arcface.ArcMarginProduct(in_feature=Di + Dt, out_feature=C, m=0.5)   # multimodal_classifier.py:22
+    with torch.no_grad():
+        head.weight.copy_(torch.randn(C, Di + Dt, generator=g) * 0.1)
+    label = torch.randint(0, C, (B,), generator=g)
+    final = torch.cat((F.normalize(img, p=2, dim=1), F.normalize(txt, p=2, dim=1)), 1)   # :54-56
+    logits = head(final, label)
+    loss = torch.nn.CrossEntropyLoss()(logits, label)
+    loss.backward()
+    npz("glue_0.npz", img=img, txt=txt, weight=head.weight, label=label, final=final, logits=logits, loss=loss,
+        dimg=img.grad, dtxt=txt.grad, dw=head.weight.grad)
+
+
+def gen_optim():
+    g = torch.Generator().manual_seed(9)
+    ps = [torch.nn.Parameter(torch.randn(5, 7, generator=g)), torch.nn.Parameter(torch.randn(11, generator=g)),
+          torch.nn.Parameter(torch.randn(3, 2, 2, generator=g))]
+    T = 10
+    for tag, lr0, warm in (("emb", 5e-5, 0), ("fc", 1e-2, 0.15 * T)):
+        params = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+        opt = torch.optim.AdamW(params, lr=lr0)
+        sch = get_scheduler(name="linear", optimizer=opt, num_warmup_steps=warm, num_training_steps=T)
+        gg = torch.Generator().manual_seed(10)
+        rec = dict(p0_0=params[0].detach().clone(), p0_1=params[1].detach().clone(), p0_2=params[2].detach().clone(),
+                   lr0=lr0, warmup=warm, total=T)
+        lrs = []
+        for t in range(T):
+            grads = [torch.randn(p.shape, generator=gg) for p in params]
+            for p, gr in zip(params, grads):
+                p.grad = gr.clone()
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step(); sch.step(); opt.zero_grad()
+            for j, gr in enumerate(grads):
+                rec[f"g{t}_{j}"] = gr
+            for j, p in enumerate(params):
+                rec[f"p{t + 1}_{j}"] = p.detach().clone()
+        rec["lrs"] = np.array(lrs)
+        npz(f"adamw_{tag}.npz", **rec)
+
+
+if __name__ == "__main__":
+    gen_arcface()
+    gen_nlp()
+    gen_glue()
+    gen_optim()
