@@ -1,0 +1,116 @@
+/* mmsim_hip.h -- C ABI of libmmsim_hip.so, the MI355X (gfx950) compute library under the
+ * MultimodalSimilar drop-in modules (arcface / nlp_classifier / cv_classifier / multimodal_classifier).
+ *
+ * The reference (forrestsocool/MultimodalSimilar) has no native layer: its hot path is Python over
+ * torch / transformers / timm.  Each entry point below names the reference lines whose arithmetic it
+ * replaces.  Conventions:
+ *   - every function returns 0 on success, non-zero on error; mmsim_last_error() gives the message;
+ *     arguments are validated BEFORE anything is launched;
+ *   - all pointers are device pointers (HBM) unless stated; nothing is allocated or freed here;
+ *   - `stream` is a hipStream_t (0 = default stream); launches are asynchronous on it;
+ *   - bf16 buffers are row-major with a leading dimension in ELEMENTS; rows are 16-byte aligned;
+ *   - dropout uses a counter-based generator keyed by (seed, stream_id, element index): the same triple
+ *     in forward and backward reproduces the mask, nothing is stored.
+ * The Python binding (multimodalsimilar_amd/_lib.py) is generated from this file; tests check that the
+ * library exports every symbol declared here.
+ */
+#ifndef MMSIM_HIP_H
+#define MMSIM_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library state -------------------------------------------------------------------------- */
+int mmsim_version(void);
+int mmsim_device_count(void);
+const char* mmsim_last_error(void);
+
+/* ---- dense products: torch F.linear / nn.Linear / 1x1 conv and their backward -------------------
+ * C[M,N] = alpha * op(A)[M,K] op(B)[K,N] (+bias[N]) with a fused epilogue, bf16 inputs, fp32 accumulate.
+ *   trans_a = 0: A stored [M][K] (lda >= K)      trans_a = 1: A stored [K][M] (lda >= M)
+ *   b_kmajor = 1: B stored [N][K] (nn.Linear weight layout)   b_kmajor = 0: B stored [K][N]
+ * Replaces: BERT dense layers (transformers modeling_bert.py:174-176, 289-293, 334-337, 347-351, 457-463
+ * as called from transformer_emb.py:20-24), F.linear in arcface.py:47, timm 1x1 convs under
+ * cv_classifier.py:49, nn.Linear cv_classifier.py:53 -- and autograd's dgrad / wgrad of each.
+ * epilogue: 0 none | 1 GELU(erf): aux_out <- pre-activation, C <- gelu | 2 C <- acc * gelu'(aux_in)
+ *           | 3 C <- acc + aux_in | 4 tanh.   split_k > 1 adds atomically into an f32 C (gradient buffers);
+ * accumulate != 0 makes C += result for split_k == 1 as well (f32 C only).
+ * K-major operands must be zero in [K, round_up(K,8)) of each row when K % 8 != 0. */
+int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                    void* C, int ldc, int c_is_f32, const float* bias, int epilogue, const void* aux_in,
+                    void* aux_out, int ld_aux, float alpha, int split_k, int accumulate, void* stream);
+
+/* ---- self-attention (modeling_bert.py:111-136, 164-203), head_dim 64, S in {32, 64, 128} ----------
+ * qkv: bf16 [B*S, ld_qkv] with q | k | v column blocks of width H; mask: int64 [B,S] (1 keep / 0 pad)
+ * or NULL; ctx: bf16 [B*S, ld_ctx]; lse: fp32 [B*heads*S] log-sum-exp saved for backward. */
+int mmsim_attn_fwd(const void* qkv, int ld_qkv, const long long* mask, void* ctx, int ld_ctx, float* lse, int B,
+                   int S, int heads, int H, float dropout_p, unsigned long long seed, unsigned int stream_id,
+                   void* stream);
+int mmsim_attn_bwd(const void* qkv, int ld_qkv, const long long* mask, const void* ctx, const void* dctx, int ld_ctx,
+                   const float* lse, void* dqkv, int B, int S, int heads, int H, float dropout_p,
+                   unsigned long long seed, unsigned int stream_id, void* stream);
+
+/* ---- BERT embeddings: LayerNorm(word[ids] + type[tt] + pos[0..S)) then dropout (modeling_bert.py:68-108).
+ * ids / token_types: int64 [B*S] (token_types may be NULL = zeros); tables and gamma/beta fp32; out bf16 [B*S,H].
+ * Backward accumulates (atomically) into dword [V,H], dpos [P,H], dtype [2,H], dgamma, dbeta (fp32, pre-zeroed). */
+int mmsim_embed_ln_fwd(const long long* ids, const long long* token_types, const float* word, const float* pos,
+                       const float* type, const float* gamma, const float* beta, void* out, int B, int S, int H,
+                       float eps, float dropout_p, unsigned long long seed, unsigned int stream_id, void* stream);
+int mmsim_embed_ln_bwd(const void* dout, const long long* ids, const long long* token_types, const float* word,
+                       const float* pos, const float* type, const float* gamma, float* dword, float* dpos,
+                       float* dtype, float* dgamma, float* dbeta, int B, int S, int H, float eps, float dropout_p,
+                       unsigned long long seed, unsigned int stream_id, void* stream);
+
+/* ---- y = dropout(t) + resid ; h = LayerNorm(y)  (BertSelfOutput / BertOutput, modeling_bert.py:289-293, 347-351).
+ * t, resid, y, h: bf16 [M,H]; mean/rstd: fp32 [M] saved for backward. */
+int mmsim_add_ln_fwd(const void* t, const void* resid, const float* gamma, const float* beta, void* y, void* h,
+                     float* mean, float* rstd, int M, int H, float eps, float dropout_p, unsigned long long seed,
+                     unsigned int stream_id, void* stream);
+/* dh = dh_a (+ dh_b if not NULL).  dy: gradient of y (residual branch).  dt: gradient of t, written only when
+ * dropout_p > 0 (otherwise dt == dy and the caller reuses dy).  dgamma/dbeta/dbias: fp32 [H], accumulated. */
+int mmsim_ln_bwd(const void* dh_a, const void* dh_b, const void* y, const float* mean, const float* rstd,
+                 const float* gamma, void* dy, void* dt, float* dgamma, float* dbeta, float* dbias, int M, int H,
+                 float dropout_p, unsigned long long seed, unsigned int stream_id, void* stream);
+
+/* out[n] += sum_m x[m,n]  (bias gradients) */
+int mmsim_colsum_bf16(const void* x, int ld, float* out, int M, int N, void* stream);
+
+/* ---- F.normalize(x, p=2, dim=1) (arcface.py:47, multimodal_classifier.py:54-55) and its backward.
+ * out[r, col_off + c] = post_scale * x[r,c] / max(||x_r||, eps); f32 and/or bf16 copies; inv_norm[r] saved.
+ * backward: dx (+)= (g - xh (xh.g)) * inv with g = pre_scale * dxh[r, col_off + c], xh = x * inv. */
+int mmsim_l2norm_fwd(const void* x, int x_is_bf16, int ldx, float* out_f32, void* out_bf16, int ldo, int col_off,
+                     float* inv_norm, int R, int D, float eps, float post_scale, void* stream);
+int mmsim_l2norm_bwd(const void* x, int x_is_bf16, int ldx, const float* inv_norm, const float* dxh, int ldd,
+                     int col_off, float* dx, int lddx, int R, int D, float pre_scale, int accumulate, void* stream);
+
+/* ---- ArcFace margin + scale (arcface.py:49-61) on cosine logits, in place: fp32 [B, ld].
+ * err_flag (device int) is set to 1 when a label is outside [0, C) (the reference raises there). */
+int mmsim_arcface_margin(float* logits, int ld, const long long* label, int B, int C, float s, float m,
+                         int easy_margin, int* err_flag, void* stream);
+/* Fused margin + scale + nn.CrossEntropyLoss (multimodal_classifier_train.py:188) + argmax (:191) + the
+ * gradient wrt the cosines: loss[b], argmax[b], dcos bf16 [B, ld] = grad_scale * dLoss_b/dcos (pad zeroed).
+ * dcos and argmax may be NULL (evaluation). */
+int mmsim_arcface_ce(const float* cosm, int ld, const long long* label, float* loss, long long* argmax, void* dcos,
+                     int B, int C, float s, float m, int easy_margin, float grad_scale, int* err_flag, void* stream);
+/* Backward of mmsim_arcface_margin for externally supplied dlogits (torch CrossEntropyLoss on the logits). */
+int mmsim_arcface_dlogits_to_dcos(const float* dlogits, int ld_dl, const float* cosm, int ld, const long long* label,
+                                  void* dcos, int B, int C, float s, float m, int easy_margin, void* stream);
+
+/* ---- small glue ------------------------------------------------------------------------------- */
+int mmsim_cast_f32_to_bf16(const float* x, void* y, unsigned long long n, void* stream);
+int mmsim_cast_bf16_to_f32(const void* x, float* y, unsigned long long n, void* stream);
+int mmsim_gather_cls(const void* h, void* out, int B, int S, int H, void* stream);     /* h[:,0] (modeling_bert.py:460) */
+int mmsim_scatter_cls(const void* src, void* dh, int B, int S, int H, void* stream);   /* its backward */
+int mmsim_tanh_bwd(const float* dpooled, const float* pooled, void* dpre, unsigned long long n, void* stream);
+
+/* ---- torch.optim.AdamW.step() (multimodal_classifier_train.py:152-156,161,195,199) over a flat fp32 buffer.
+ * g is multiplied by grad_scale first (1/world_size after an all-reduce sum); bf16_shadow (may be NULL)
+ * receives the updated parameters rounded to bf16 for the next forward.  n % 4 == 0.  step is 1-based. */
+int mmsim_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, unsigned long long n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,73 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the two-tower + ArcFace step.
+// Wave = 64 lanes everywhere; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+typedef __attribute__((ext_vector_type(4))) float f4;
+typedef __attribute__((ext_vector_type(16))) float f16v;
+typedef __attribute__((ext_vector_type(4))) short s4;
+typedef __attribute__((ext_vector_type(8))) short s8;
+
+#define MMSIM_OK 0
+#define MMSIM_ERR_ARG 1
+#define MMSIM_ERR_LAUNCH 2
+
+extern "C" void mmsim_set_error(const char* msg);
+int mmsim_check_launch(const char* what);
+
+#define MMSIM_REQUIRE(cond, msg)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      mmsim_set_error(msg);                      \
+      return MMSIM_ERR_ARG;                      \
+    }                                            \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact-erf GELU and its derivative (HF "gelu", modeling_bert.py:334-337)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+__device__ __forceinline__ float silu_grad_f(float x) {
+  const float s = sigmoid_f(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+// Counter-based dropout RNG: one 32-bit hash per element, keyed by (seed, stream, index).
+// keep iff hash >= threshold; threshold = p * 2^32.  Deterministic, recomputed in backward.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint32_t stream, uint64_t idx) {
+  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+  uint32_t h = hash32(lo ^ (uint32_t)seed);
+  h = hash32(h + hi * 0x9E3779B9U + stream * 0x85EBCA6BU + (uint32_t)(seed >> 32));
+  return h;
+}
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t stream, uint64_t idx, uint32_t thresh) {
+  return rng_u32(seed, stream, idx) >= thresh;
+}

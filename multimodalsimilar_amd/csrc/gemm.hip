@@ -1,0 +1,278 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = op(A)[M,K] * op(B)[K,N]  (+ fused epilogues), fp32 accumulate.
+//
+// One kernel template serves the three products of a Linear / 1x1-conv layer without any transposed
+// copies in HBM:
+//   forward   Y  = X  W^T      A k-major [M][K],            B k-major  [N][K]   (TA=0, TB=1)
+//   dgrad     dX = dY W        A k-major [M][N_out as K],   B row-major [K][N]  (TA=0, TB=0)
+//   wgrad     dW = dY^T X      A stored  [K][M],            B stored   [K][N]   (TA=1, TB=0)
+// k-major operands are staged [128 rows][64 k] (160-B pitch, conflict-free ds_read_b128); operands whose
+// reduction index is the slow (row) index are staged as they lie in memory, [64 k][128 cols] with a 32-B
+// column-block XOR swizzle, and fed to the MFMA through the hardware transposing read ds_read_b64_tr_b16.
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 tiles.
+// The MFMA is issued with the operands swapped (D^T = B^T A^T) so every lane owns 4 CONSECUTIVE output
+// columns of one row: 8-byte bf16 / 16-byte f32 stores and float4 bias loads.
+// Global->LDS staging is register-staged and split (issue loads for tile t+1, compute tile t, then write):
+// one barrier per K-step on double-buffered LDS.  Blocks are remapped so that the tiles an XCD works on
+// are neighbours (shared A panel in that XCD's L2).
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define KM_PITCH 160                       // bytes per k-major row (128 B data + 32 B pad)
+#define OP_STAGE_BYTES (BM * KM_PITCH)     // 20480 >= 64*256 (transposed-staged operand)
+#define STAGE_BYTES (2 * OP_STAGE_BYTES)
+
+struct GemmParams {
+  const bf16* A; const bf16* B; void* C; const float* bias; const bf16* aux_in; bf16* aux_out;
+  int M, N, K, lda, ldb, ldc, ld_aux;
+  int c_f32, epi, atomic, accum, k_per_split, tiles_m, tiles_n;
+  float alpha;
+};
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_MUL_GELU_GRAD = 2, EPI_ADD = 3, EPI_TANH = 4 };
+
+__device__ __forceinline__ int tr_key(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+template <bool TRANS>
+__device__ __forceinline__ void load_tile(const bf16* __restrict__ X, int ld, int r0, int R, int k0, int kend,
+                                          int tid, uint4 (&reg)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (!TRANS) {
+      const int row = c >> 3, kc = c & 7;
+      const int gr = r0 + row, gk = k0 + kc * 8;
+      if (gr < R && gk < kend) v = *reinterpret_cast<const uint4*>(X + (size_t)gr * ld + gk);
+    } else {
+      const int krow = c >> 4, rc = c & 15;
+      const int gk = k0 + krow, gr = r0 + rc * 8;
+      if (gk < kend && gr < R) v = *reinterpret_cast<const uint4*>(X + (size_t)gk * ld + gr);
+    }
+    reg[i] = v;
+  }
+}
+
+template <bool TRANS>
+__device__ __forceinline__ void store_tile(char* lds, int tid, const uint4 (&reg)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    if (!TRANS) {
+      const int row = c >> 3, kc = c & 7;
+      *reinterpret_cast<uint4*>(lds + row * KM_PITCH + kc * 16) = reg[i];
+    } else {
+      const int krow = c >> 4, rc = c & 15;
+      const int pos = (((rc >> 1) ^ tr_key(krow)) << 1) | (rc & 1);
+      *reinterpret_cast<uint4*>(lds + krow * 256 + pos * 16) = reg[i];
+    }
+  }
+}
+
+// fragment of 16 "rows" (row index = lane&15) x 32 k for k-step ks, rows starting at rbase (multiple of 16)
+template <bool TRANS>
+__device__ __forceinline__ bf8 read_frag(const char* lds, int rbase, int ks, int lane) {
+  if (!TRANS) {
+    const int row = rbase + (lane & 15), kc = ks * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf8*>(lds + row * KM_PITCH + kc * 16);
+  } else {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int k = ks * 32 + 8 * g + q;
+    const int cb = rbase >> 4;
+    const int off = k * 256 + ((cb ^ tr_key(k)) << 5) + p * 8;
+    typedef s4 __attribute__((address_space(3))) * lds_s4_ptr;
+    s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(lds + off));
+    s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(lds + off + 4 * 256));
+    s8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(bf8, r);
+  }
+}
+
+template <bool TA, bool TB_KMAJOR>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware bijective remap of the 1-D grid onto tiles
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tm = wg / p.tiles_n, tn = wg % p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = blockIdx.y * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  f4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[4], rb[4];
+  load_tile<TA>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
+  load_tile<!TB_KMAJOR>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb);
+  store_tile<TA>(smem, tid, ra);
+  store_tile<!TB_KMAJOR>(smem + OP_STAGE_BYTES, tid, rb);
+  __syncthreads();
+
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    const char* la = smem + cur * STAGE_BYTES;
+    const char* lb = la + OP_STAGE_BYTES;
+    if (t + 1 < nk) {
+      load_tile<TA>(p.A, p.lda, m0, p.M, kbeg + (t + 1) * BK, kend, tid, ra);
+      load_tile<!TB_KMAJOR>(p.B, p.ldb, n0, p.N, kbeg + (t + 1) * BK, kend, tid, rb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = read_frag<TA>(la, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = read_frag<!TB_KMAJOR>(lb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nk) {
+      char* na = smem + (cur ^ 1) * STAGE_BYTES;
+      store_tile<TA>(na, tid, ra);
+      store_tile<!TB_KMAJOR>(na + OP_STAGE_BYTES, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane owns row m = .. + (lane&15), columns n = .. + (lane>>4)*4 + {0,1,2,3}
+  const bool add_bias = (p.bias != nullptr) && (blockIdx.y == 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      if (n >= p.N) continue;
+      float v[4] = {acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
+      const bool full = (n + 3 < p.N);
+      if (add_bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.N) v[e] += p.bias[n + e];
+      }
+      if (p.epi == EPI_GELU) {
+        bf16* ao = p.aux_out + (size_t)m * p.ld_aux + n;
+        if (full) {
+          bf4 pre = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+          *reinterpret_cast<bf4*>(ao) = pre;
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) ao[e] = f2bf(v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_f(bf2f(f2bf(v[e])));   // gelu of the stored (rounded) pre-activation
+      } else if (p.epi == EPI_MUL_GELU_GRAD) {
+        const bf16* ai = p.aux_in + (size_t)m * p.ld_aux + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.N) v[e] *= gelu_grad_f(bf2f(ai[e]));
+      } else if (p.epi == EPI_ADD) {
+        const bf16* ai = p.aux_in + (size_t)m * p.ld_aux + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.N) v[e] += bf2f(ai[e]);
+      } else if (p.epi == EPI_TANH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+      }
+      if (p.c_f32) {
+        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+        if (p.atomic) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) atomicAdd(c + e, v[e]);
+        } else if (full) {
+          float4 o = make_float4(v[0], v[1], v[2], v[3]);
+          if (p.accum) {
+            const float4 old = *reinterpret_cast<const float4*>(c);
+            o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+          }
+          *reinterpret_cast<float4*>(c) = o;
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) c[e] = p.accum ? c[e] + v[e] : v[e];
+        }
+      } else {
+        bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
+        if (full) {
+          bf4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+          *reinterpret_cast<bf4*>(c) = o;
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) c[e] = f2bf(v[e]);
+        }
+      }
+    }
+  }
+}
+
+// C-ABI -- see include/mmsim_hip.h for the contract.
+extern "C" int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B,
+                               int ldb, void* C, int ldc, int c_is_f32, const float* bias, int epilogue,
+                               const void* aux_in, void* aux_out, int ld_aux, float alpha, int split_k,
+                               int accumulate, void* stream) {
+  MMSIM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: M, N, K must be positive");
+  MMSIM_REQUIRE(A && B && C, "gemm: null operand");
+  MMSIM_REQUIRE((lda % 8) == 0 && (ldb % 8) == 0, "gemm: lda/ldb must be multiples of 8 elements (16-byte rows)");
+  MMSIM_REQUIRE((ldc % 4) == 0, "gemm: ldc must be a multiple of 4");
+  MMSIM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
+                "gemm: operands must be 16-byte aligned");
+  MMSIM_REQUIRE(epilogue >= 0 && epilogue <= 4, "gemm: unknown epilogue");
+  MMSIM_REQUIRE(!(epilogue == EPI_GELU) || aux_out, "gemm: GELU epilogue needs aux_out (pre-activation)");
+  MMSIM_REQUIRE(!(epilogue == EPI_MUL_GELU_GRAD || epilogue == EPI_ADD) || aux_in, "gemm: epilogue needs aux_in");
+  MMSIM_REQUIRE(epilogue == EPI_NONE || (ld_aux % 4) == 0 || epilogue == EPI_TANH, "gemm: ld_aux must be a multiple of 4");
+  MMSIM_REQUIRE(split_k >= 1, "gemm: split_k >= 1");
+  MMSIM_REQUIRE(split_k == 1 || (c_is_f32 && epilogue == EPI_NONE), "gemm: split-K needs f32 output and no epilogue");
+  MMSIM_REQUIRE(!accumulate || c_is_f32, "gemm: accumulate needs f32 output");
+  // leading dimensions must cover the extents rounded up to the 8-element load granule
+  const int a_cols = trans_a ? M : K, b_cols = b_kmajor ? K : N;
+  MMSIM_REQUIRE(lda >= ((a_cols + 7) & ~7) && ldb >= ((b_cols + 7) & ~7), "gemm: leading dimension too small");
+  GemmParams p;
+  p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = C; p.bias = bias;
+  p.aux_in = (const bf16*)aux_in; p.aux_out = (bf16*)aux_out;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux;
+  p.c_f32 = c_is_f32; p.epi = epilogue; p.atomic = split_k > 1; p.accum = accumulate; p.alpha = alpha;
+  p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+  int kps = (K + split_k - 1) / split_k;
+  kps = ((kps + BK - 1) / BK) * BK;
+  p.k_per_split = kps;
+  const int splits = (K + kps - 1) / kps;
+  dim3 grid(p.tiles_m * p.tiles_n, splits), block(256);
+  const size_t lds = 2 * STAGE_BYTES;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_done = false;
+  if (!attr_done) {   // 80 KiB of dynamic LDS per block needs the opt-in on every instantiation
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  if (!trans_a && b_kmajor) {
+    hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, lds, s, p);
+  } else if (!trans_a && !b_kmajor) {
+    hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, lds, s, p);
+  } else if (trans_a && !b_kmajor) {
+    hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, lds, s, p);
+  } else {
+    hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, lds, s, p);
+  }
+  return mmsim_check_launch("gemm_bf16");
+}

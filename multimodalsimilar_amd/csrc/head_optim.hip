@@ -1,0 +1,293 @@
+// ArcFace head epilogues, fused softmax-cross-entropy, small glue kernels and the fused AdamW step (gfx950).
+//   arcface_margin      logits = s * (target ? margin(cos) : cos)                     arcface.py:49-61
+//   arcface_ce          loss_b, argmax_b and dcos (bf16) from cos without materialising logits / softmax
+//   dlogits_to_dcos     backward of arcface_margin for externally supplied dlogits
+//   adamw               torch.optim.AdamW semantics over a flat fp32 buffer, also refreshes the bf16 shadow
+#include "common.h"
+
+struct Margin { float s, cos_m, sin_m, th, mm; int easy; };
+
+__device__ __forceinline__ float margin_fwd(float c, const Margin& m, float* slope) {
+  const float sine = sqrtf(1.0f - c * c);
+  const float phi = c * m.cos_m - sine * m.sin_m;
+  const bool take = m.easy ? (c > 0.f) : ((c - m.th) > 0.f);
+  if (slope) *slope = take ? (m.cos_m + m.sin_m * c / sine) : 1.0f;
+  return take ? phi : (m.easy ? c : c - m.mm);
+}
+
+__global__ __launch_bounds__(256) void arcface_margin_kernel(float* z, int ld, const int64_t* label, int B, int C, Margin m,
+                                                             int* err) {
+  const int b = blockIdx.y;
+  const int64_t y = label[b];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (y < 0 || y >= C)) atomicExch(err, 1);
+  for (int c = (blockIdx.x * 256 + threadIdx.x) * 4; c < C; c += gridDim.x * 1024) {
+    float* p = z + (size_t)b * ld + c;
+    float4 v = *reinterpret_cast<float4*>(p);
+    float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (c + e == y) a[e] = margin_fwd(a[e], m, nullptr);
+      a[e] *= m.s;
+    }
+    if (c + 3 < C) *reinterpret_cast<float4*>(p) = make_float4(a[0], a[1], a[2], a[3]);
+    else
+      for (int e = 0; e < 4 && c + e < C; ++e) p[e] = a[e];
+  }
+}
+
+__device__ __forceinline__ void block_reduce_ms(float& mx, float& sm, int& am, float* sh_f, int* sh_i) {
+  // combine (max, sumexp, argmax) over the block
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(mx, o, 64), os = __shfl_xor(sm, o, 64);
+    const int oa = __shfl_xor(am, o, 64);
+    const float nm = fmaxf(mx, om);
+    sm = sm * __expf(mx - nm) + os * __expf(om - nm);
+    if (om > mx || (om == mx && oa < am)) am = oa;
+    mx = nm;
+  }
+  if (lane == 0) { sh_f[wv] = mx; sh_f[4 + wv] = sm; sh_i[wv] = am; }
+  __syncthreads();
+  float M = sh_f[0], S = sh_f[4];
+  int A = sh_i[0];
+  for (int k = 1; k < 4; ++k) {
+    const float om = sh_f[k], os = sh_f[4 + k];
+    const int oa = sh_i[k];
+    const float nm = fmaxf(M, om);
+    S = S * __expf(M - nm) + os * __expf(om - nm);
+    if (om > M || (om == M && oa < A)) A = oa;
+    M = nm;
+  }
+  mx = M; sm = S; am = A;
+}
+
+// one block per row.  cos: f32 [B, ld].  dcos: bf16 [B, ld] (pad columns C..ld-1 zeroed).
+__global__ __launch_bounds__(256) void arcface_ce_kernel(const float* cosm, int ld, const int64_t* label, float* loss,
+                                                         long long* argmax, bf16* dcos, int C, Margin m, float gscale,
+                                                         int* err) {
+  __shared__ float sh_f[8];
+  __shared__ int sh_i[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t y = label[b];
+  const bool bad = (y < 0 || y >= C);
+  if (tid == 0 && bad) atomicExch(err, 1);
+  const float* row = cosm + (size_t)b * ld;
+  float zt = 0.f, slope = 1.f;
+  if (!bad) zt = margin_fwd(row[y], m, &slope) * m.s;
+  float mx = -3.0e38f, sm = 0.f;
+  int am = 0x7fffffff;
+  for (int c = tid * 4; c < C; c += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(row + c);
+    const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (c + e < C) {
+        const float z = (c + e == y) ? zt : a[e] * m.s;
+        if (z > mx) { sm = sm * __expf(mx - z) + 1.0f; mx = z; am = c + e; }
+        else sm += __expf(z - mx);
+      }
+    }
+  }
+  block_reduce_ms(mx, sm, am, sh_f, sh_i);
+  const float lse = mx + __logf(sm);
+  if (tid == 0) {
+    loss[b] = bad ? 0.f : (lse - zt);
+    if (argmax) argmax[b] = am;
+  }
+  if (!dcos) return;
+  bf16* drow = dcos + (size_t)b * ld;
+  for (int c = tid * 4; c < ld; c += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(row + c);
+    const float a[4] = {v.x, v.y, v.z, v.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (c + e < C) {
+        const bool tgt = (c + e == y);
+        const float z = tgt ? zt : a[e] * m.s;
+        float g = __expf(z - lse) - (tgt ? 1.0f : 0.0f);
+        g *= gscale * m.s * (tgt ? slope : 1.0f);
+        o[e] = g;
+      } else o[e] = 0.f;
+    }
+    bf4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+    *reinterpret_cast<bf4*>(drow + c) = ob;
+  }
+}
+
+// dcos = dlogits * s * (target ? slope(cos) : 1)   -> bf16 [B, ld] with zeroed pad
+__global__ __launch_bounds__(256) void dlogits_to_dcos_kernel(const float* dlogits, int ld_dl, const float* cosm, int ld,
+                                                              const int64_t* label, bf16* dcos, int C, Margin m) {
+  const int b = blockIdx.y;
+  const int64_t y = label ? label[b] : -1;
+  for (int c = (blockIdx.x * 256 + threadIdx.x) * 4; c < ld; c += gridDim.x * 1024) {
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (c + e < C) {
+        float g = dlogits[(size_t)b * ld_dl + c + e] * m.s;
+        if (c + e == y) { float sl; margin_fwd(cosm[(size_t)b * ld + c + e], m, &sl); g *= sl; }
+        o[e] = g;
+      } else o[e] = 0.f;
+    }
+    bf4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+    *reinterpret_cast<bf4*>(dcos + (size_t)b * ld + c) = ob;
+  }
+}
+
+// ---------------------------------------------------------------- glue
+__global__ void cast_f32_bf16_kernel(const float* x, bf16* y, size_t n) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    bf4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+    *reinterpret_cast<bf4*>(y + i) = o;
+  }
+  if (i < n) for (size_t k = i; k < n && k < i + 4; ++k) y[k] = f2bf(x[k]);
+}
+__global__ void cast_bf16_f32_kernel(const bf16* x, float* y, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = bf2f(x[i]);
+}
+// rows b*S (the [CLS] token) of h [B*S, H] -> out [B, H]
+__global__ void gather_cls_kernel(const bf16* h, bf16* out, int S, int H) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < H; c += blockDim.x) out[(size_t)b * H + c] = h[(size_t)b * S * H + c];
+}
+// dh [B*S, H] = 0 except row b*S = src[b]
+__global__ void scatter_cls_kernel(const bf16* src, bf16* dh, int S, int H) {
+  const int row = blockIdx.x, b = row / S;
+  const bool cls = (row % S) == 0;
+  for (int c = threadIdx.x; c < H; c += blockDim.x) dh[(size_t)row * H + c] = cls ? src[(size_t)b * H + c] : f2bf(0.f);
+}
+// dpre = dpooled * (1 - pooled^2)
+__global__ void tanh_bwd_kernel(const float* dpooled, const float* pooled, bf16* dpre, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float p = pooled[i]; dpre[i] = f2bf(dpooled[i] * (1.0f - p * p)); }
+}
+
+// ---------------------------------------------------------------- fused AdamW over a flat buffer
+// p <- p(1 - lr wd); m <- b1 m + (1-b1) g; v <- b2 v + (1-b2) g^2; p <- p - (lr/bc1) m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16* shadow, size_t n,
+                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                    float rsqrt_bc2, float gscale) {
+  size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const size_t stride = (size_t)gridDim.x * 1024;
+  for (; i < n; i += stride) {   // n is padded to a multiple of 4 by the host
+    const float4 pg = *reinterpret_cast<const float4*>(g + i);
+    float4 pp = *reinterpret_cast<const float4*>(p + i), pm = *reinterpret_cast<const float4*>(m + i),
+           pv = *reinterpret_cast<const float4*>(v + i);
+    float P[4] = {pp.x, pp.y, pp.z, pp.w}, G[4] = {pg.x, pg.y, pg.z, pg.w}, Mm[4] = {pm.x, pm.y, pm.z, pm.w},
+          V[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gg = G[e] * gscale;
+      P[e] *= (1.0f - lr * wd);
+      Mm[e] = b1 * Mm[e] + (1.0f - b1) * gg;
+      V[e] = b2 * V[e] + (1.0f - b2) * gg * gg;
+      const float denom = sqrtf(V[e]) * rsqrt_bc2 + eps;
+      P[e] -= (lr / bc1) * (Mm[e] / denom);
+    }
+    *reinterpret_cast<float4*>(p + i) = make_float4(P[0], P[1], P[2], P[3]);
+    *reinterpret_cast<float4*>(m + i) = make_float4(Mm[0], Mm[1], Mm[2], Mm[3]);
+    *reinterpret_cast<float4*>(v + i) = make_float4(V[0], V[1], V[2], V[3]);
+    if (shadow) {
+      bf4 o = {f2bf(P[0]), f2bf(P[1]), f2bf(P[2]), f2bf(P[3])};
+      *reinterpret_cast<bf4*>(shadow + i) = o;
+    }
+  }
+}
+
+// ================================================================= C-ABI
+static Margin mk_margin(float s, float m, int easy) {
+  Margin r;
+  r.s = s; r.cos_m = cosf(m); r.sin_m = sinf(m);
+  r.th = cosf(3.14159265358979323846f - m); r.mm = sinf(3.14159265358979323846f - m) * m; r.easy = easy;
+  // use double for the constants the reference computes with python floats
+  r.cos_m = (float)cos((double)m); r.sin_m = (float)sin((double)m);
+  r.th = (float)cos(3.14159265358979323846 - (double)m); r.mm = (float)(sin(3.14159265358979323846 - (double)m) * (double)m);
+  return r;
+}
+
+extern "C" int mmsim_arcface_margin(float* logits, int ld, const long long* label, int B, int C, float s, float m,
+                                    int easy_margin, int* err_flag, void* stream) {
+  MMSIM_REQUIRE(logits && label && err_flag && B > 0 && C > 0, "arcface_margin: bad arguments");
+  MMSIM_REQUIRE(ld % 4 == 0 && ld >= C, "arcface_margin: ld must be a multiple of 4 and >= C");
+  int gx = (C + 1023) / 1024; if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(arcface_margin_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, logits, ld,
+                     (const int64_t*)label, B, C, mk_margin(s, m, easy_margin), err_flag);
+  return mmsim_check_launch("arcface_margin");
+}
+
+extern "C" int mmsim_arcface_ce(const float* cosm, int ld, const long long* label, float* loss, long long* argmax,
+                                void* dcos, int B, int C, float s, float m, int easy_margin, float grad_scale,
+                                int* err_flag, void* stream) {
+  MMSIM_REQUIRE(cosm && label && loss && err_flag && B > 0 && C > 0, "arcface_ce: bad arguments");
+  MMSIM_REQUIRE(ld % 8 == 0 && ld >= C, "arcface_ce: ld must be a multiple of 8 and >= C");
+  hipLaunchKernelGGL(arcface_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, cosm, ld, (const int64_t*)label, loss,
+                     argmax, (bf16*)dcos, C, mk_margin(s, m, easy_margin), grad_scale, err_flag);
+  return mmsim_check_launch("arcface_ce");
+}
+
+extern "C" int mmsim_arcface_dlogits_to_dcos(const float* dlogits, int ld_dl, const float* cosm, int ld,
+                                             const long long* label, void* dcos, int B, int C, float s, float m,
+                                             int easy_margin, void* stream) {
+  MMSIM_REQUIRE(dlogits && cosm && dcos && B > 0 && C > 0, "dlogits_to_dcos: bad arguments");
+  MMSIM_REQUIRE(ld % 8 == 0 && ld >= C && ld_dl >= C, "dlogits_to_dcos: bad leading dimensions");
+  int gx = (ld + 1023) / 1024; if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(dlogits_to_dcos_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, dlogits, ld_dl, cosm, ld,
+                     (const int64_t*)label, (bf16*)dcos, C, mk_margin(s, m, easy_margin));
+  return mmsim_check_launch("dlogits_to_dcos");
+}
+
+static int grid_for(size_t n, int per_block) {
+  size_t g = (n + per_block - 1) / per_block;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int mmsim_cast_f32_to_bf16(const float* x, void* y, unsigned long long n, void* stream) {
+  MMSIM_REQUIRE(x && y, "cast: null");
+  if (n == 0) return MMSIM_OK;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)y, (size_t)n);
+  return mmsim_check_launch("cast_f32_to_bf16");
+}
+extern "C" int mmsim_cast_bf16_to_f32(const void* x, float* y, unsigned long long n, void* stream) {
+  MMSIM_REQUIRE(x && y, "cast: null");
+  if (n == 0) return MMSIM_OK;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, y, (size_t)n);
+  return mmsim_check_launch("cast_bf16_to_f32");
+}
+extern "C" int mmsim_gather_cls(const void* h, void* out, int B, int S, int H, void* stream) {
+  MMSIM_REQUIRE(h && out && B > 0, "gather_cls: bad arguments");
+  hipLaunchKernelGGL(gather_cls_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16*)h, (bf16*)out, S, H);
+  return mmsim_check_launch("gather_cls");
+}
+extern "C" int mmsim_scatter_cls(const void* src, void* dh, int B, int S, int H, void* stream) {
+  MMSIM_REQUIRE(src && dh && B > 0, "scatter_cls: bad arguments");
+  hipLaunchKernelGGL(scatter_cls_kernel, dim3(B * S), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, (bf16*)dh, S, H);
+  return mmsim_check_launch("scatter_cls");
+}
+extern "C" int mmsim_tanh_bwd(const float* dpooled, const float* pooled, void* dpre, unsigned long long n, void* stream) {
+  MMSIM_REQUIRE(dpooled && pooled && dpre, "tanh_bwd: null");
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dpooled, pooled,
+                     (bf16*)dpre, (size_t)n);
+  return mmsim_check_launch("tanh_bwd");
+}
+
+extern "C" int mmsim_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, unsigned long long n,
+                                float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                float grad_scale, void* stream) {
+  MMSIM_REQUIRE(p && g && m && v, "adamw: null operand");
+  MMSIM_REQUIRE(n % 4 == 0, "adamw: flat buffer length must be a multiple of 4");
+  MMSIM_REQUIRE(step >= 1, "adamw: step is 1-based");
+  if (n == 0) return MMSIM_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)bf16_shadow,
+                     (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+  return mmsim_check_launch("adamw");
+}

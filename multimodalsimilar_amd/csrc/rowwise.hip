@@ -1,0 +1,456 @@
+// HBM-bound row kernels of the text tower and the head for gfx950: one wave (64 lanes) per row, 4-element
+// vectors per lane, fp32 statistics, wave shuffles for the row reductions, per-wave register partials +
+// one atomic per column per block for the column reductions (dgamma / dbeta / dbias).
+//   embed_ln_fwd / embed_ln_bwd        BERT embeddings  (modeling_bert.py:68-108)
+//   add_ln_fwd / ln_bwd                LayerNorm(dropout(t) + residual)  (modeling_bert.py:289-293, 347-351)
+//   colsum                             bias gradients
+//   l2norm_fwd / l2norm_bwd            F.normalize rows (arcface.py:47, multimodal_classifier.py:54-55)
+#include "common.h"
+
+#define MAXC 8   // max 4-element chunks per lane: H <= 2048
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16* p) {
+  const bf4 v = *reinterpret_cast<const bf4*>(p);
+  return make_float4(bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3]));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16* p, float4 v) {
+  bf4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+  *reinterpret_cast<bf4*>(p) = o;
+}
+
+struct Drop { unsigned long long seed; unsigned int stream, thresh; float inv_keep; };
+static Drop make_drop(float p, unsigned long long seed, unsigned int stream) {
+  Drop d; d.seed = seed; d.stream = stream;
+  d.thresh = p > 0.f ? (unsigned int)((double)p * 4294967296.0) : 0u;
+  d.inv_keep = 1.0f / (1.0f - p);
+  return d;
+}
+__device__ __forceinline__ float4 drop4(float4 v, const Drop& d, unsigned long long idx) {
+  if (!d.thresh) return v;
+  v.x = drop_keep(d.seed, d.stream, idx, d.thresh) ? v.x * d.inv_keep : 0.f;
+  v.y = drop_keep(d.seed, d.stream, idx + 1, d.thresh) ? v.y * d.inv_keep : 0.f;
+  v.z = drop_keep(d.seed, d.stream, idx + 2, d.thresh) ? v.z * d.inv_keep : 0.f;
+  v.w = drop_keep(d.seed, d.stream, idx + 3, d.thresh) ? v.w * d.inv_keep : 0.f;
+  return v;
+}
+
+// normalise the row held in v[] (nc chunks per lane); returns mean / rstd
+__device__ __forceinline__ void row_stats(const float4 (&v)[MAXC], int nc, int H, float eps, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c < nc) s += v[c].x + v[c].y + v[c].z + v[c].w;
+  mean = wave_sum(s) / H;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c < nc) {
+      const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
+      q += a * a + b * b + cc * cc + d * d;
+    }
+  rstd = rsqrtf(wave_sum(q) / H + eps);
+}
+
+// ---------------------------------------------------------------- embeddings + LayerNorm
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, const int64_t* tts, const float* word,
+                                                           const float* pos, const float* type, const float* gamma,
+                                                           const float* beta, bf16* out, int M, int S, int H, float eps,
+                                                           Drop dr) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= M) return;
+  const int64_t id = ids[row], tt = tts ? tts[row] : 0;
+  const int s = row % S;
+  float4 v[MAXC];
+  int nc = 0;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int col = lane * 4 + c * 256;
+    if (col < H) {
+      const float4 a = ld4(word + (size_t)id * H + col), b = ld4(pos + (size_t)s * H + col), t = ld4(type + (size_t)tt * H + col);
+      v[c] = make_float4(a.x + b.x + t.x, a.y + b.y + t.y, a.z + b.z + t.z, a.w + b.w + t.w);
+      nc = c + 1;
+    }
+  }
+  float mean, rstd;
+  row_stats(v, nc, H, eps, mean, rstd);
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int col = lane * 4 + c * 256;
+    if (col < H) {
+      const float4 g = ld4(gamma + col), bb = ld4(beta + col);
+      float4 o = make_float4((v[c].x - mean) * rstd * g.x + bb.x, (v[c].y - mean) * rstd * g.y + bb.y,
+                             (v[c].z - mean) * rstd * g.z + bb.z, (v[c].w - mean) * rstd * g.w + bb.w);
+      o = drop4(o, dr, (unsigned long long)row * H + col);
+      st4(out + (size_t)row * H + col, o);
+    }
+  }
+}
+
+// backward of the embedding block.  Each wave owns one position s and a chunk of the batch, so the
+// position/type/gamma/beta gradients accumulate in registers and leave as one atomic row per wave.
+__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* dout, const int64_t* ids, const int64_t* tts,
+                                                           const float* word, const float* pos, const float* type,
+                                                           const float* gamma, float* dword, float* dpos, float* dtype,
+                                                           float* dgamma, float* dbeta, int B, int S, int H, float eps,
+                                                           int bchunk, Drop dr) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int gw = blockIdx.x * 4 + wv;
+  const int nchunks = (B + bchunk - 1) / bchunk;
+  if (gw >= S * nchunks) return;
+  const int s = gw % S, b0 = (gw / S) * bchunk, b1 = min(B, b0 + bchunk);
+  float4 apos[MAXC], at0[MAXC], at1[MAXC], ag[MAXC], ab[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) apos[c] = at0[c] = at1[c] = ag[c] = ab[c] = make_float4(0, 0, 0, 0);
+  for (int b = b0; b < b1; ++b) {
+    const int row = b * S + s;
+    const int64_t id = ids[row], tt = tts ? tts[row] : 0;
+    float4 v[MAXC], g[MAXC];
+    int nc = 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int col = lane * 4 + c * 256;
+      if (col < H) {
+        const float4 a = ld4(word + (size_t)id * H + col), p2 = ld4(pos + (size_t)s * H + col), t = ld4(type + (size_t)tt * H + col);
+        v[c] = make_float4(a.x + p2.x + t.x, a.y + p2.y + t.y, a.z + p2.z + t.z, a.w + p2.w + t.w);
+        g[c] = drop4(ld4(dout + (size_t)row * H + col), dr, (unsigned long long)row * H + col);
+        nc = c + 1;
+      }
+    }
+    float mean, rstd;
+    row_stats(v, nc, H, eps, mean, rstd);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int col = lane * 4 + c * 256;
+      if (col < H) {
+        const float4 gm = ld4(gamma + col);
+        float4 xh = make_float4((v[c].x - mean) * rstd, (v[c].y - mean) * rstd, (v[c].z - mean) * rstd, (v[c].w - mean) * rstd);
+        ag[c].x += g[c].x * xh.x; ag[c].y += g[c].y * xh.y; ag[c].z += g[c].z * xh.z; ag[c].w += g[c].w * xh.w;
+        ab[c].x += g[c].x; ab[c].y += g[c].y; ab[c].z += g[c].z; ab[c].w += g[c].w;
+        g[c] = make_float4(g[c].x * gm.x, g[c].y * gm.y, g[c].z * gm.z, g[c].w * gm.w);   // dxhat
+        s1 += g[c].x + g[c].y + g[c].z + g[c].w;
+        s2 += g[c].x * xh.x + g[c].y * xh.y + g[c].z * xh.z + g[c].w * xh.w;
+        v[c] = xh;
+      }
+    }
+    s1 = wave_sum(s1) / H; s2 = wave_sum(s2) / H;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int col = lane * 4 + c * 256;
+      if (col < H) {
+        const float4 de = make_float4(rstd * (g[c].x - s1 - v[c].x * s2), rstd * (g[c].y - s1 - v[c].y * s2),
+                                      rstd * (g[c].z - s1 - v[c].z * s2), rstd * (g[c].w - s1 - v[c].w * s2));
+        float* dw = dword + (size_t)id * H + col;
+        atomicAdd(dw, de.x); atomicAdd(dw + 1, de.y); atomicAdd(dw + 2, de.z); atomicAdd(dw + 3, de.w);
+        apos[c].x += de.x; apos[c].y += de.y; apos[c].z += de.z; apos[c].w += de.w;
+        if (tt == 0) { at0[c].x += de.x; at0[c].y += de.y; at0[c].z += de.z; at0[c].w += de.w; }
+        else { at1[c].x += de.x; at1[c].y += de.y; at1[c].z += de.z; at1[c].w += de.w; }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int col = lane * 4 + c * 256;
+    if (col < H) {
+      float* a = dpos + (size_t)s * H + col;
+      atomicAdd(a, apos[c].x); atomicAdd(a + 1, apos[c].y); atomicAdd(a + 2, apos[c].z); atomicAdd(a + 3, apos[c].w);
+      a = dtype + col;
+      atomicAdd(a, at0[c].x); atomicAdd(a + 1, at0[c].y); atomicAdd(a + 2, at0[c].z); atomicAdd(a + 3, at0[c].w);
+      a = dtype + H + col;
+      atomicAdd(a, at1[c].x); atomicAdd(a + 1, at1[c].y); atomicAdd(a + 2, at1[c].z); atomicAdd(a + 3, at1[c].w);
+      a = dgamma + col;
+      atomicAdd(a, ag[c].x); atomicAdd(a + 1, ag[c].y); atomicAdd(a + 2, ag[c].z); atomicAdd(a + 3, ag[c].w);
+      a = dbeta + col;
+      atomicAdd(a, ab[c].x); atomicAdd(a + 1, ab[c].y); atomicAdd(a + 2, ab[c].z); atomicAdd(a + 3, ab[c].w);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- y = dropout(t) + resid ; h = LN(y)
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16* t, const bf16* resid, const float* gamma,
+                                                         const float* beta, bf16* y, bf16* hout, float* mean_o,
+                                                         float* rstd_o, int M, int H, float eps, Drop dr) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= M) return;
+  float4 v[MAXC];
+  int nc = 0;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int col = lane * 4 + c * 256;
+    if (col < H) {
+      float4 a = drop4(ld4(t + (size_t)row * H + col), dr, (unsigned long long)row * H + col);
+      const float4 r = ld4(resid + (size_t)row * H + col);
+      a = make_float4(a.x + r.x, a.y + r.y, a.z + r.z, a.w + r.w);
+      // statistics are taken on the bf16-rounded sum that backward will read back
+      bf4 rb = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w)};
+      *reinterpret_cast<bf4*>(y + (size_t)row * H + col) = rb;
+      v[c] = make_float4(bf2f(rb[0]), bf2f(rb[1]), bf2f(rb[2]), bf2f(rb[3]));
+      nc = c + 1;
+    }
+  }
+  float mean, rstd;
+  row_stats(v, nc, H, eps, mean, rstd);
+  if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int col = lane * 4 + c * 256;
+    if (col < H) {
+      const float4 g = ld4(gamma + col), bb = ld4(beta + col);
+      st4(hout + (size_t)row * H + col,
+          make_float4((v[c].x - mean) * rstd * g.x + bb.x, (v[c].y - mean) * rstd * g.y + bb.y,
+                      (v[c].z - mean) * rstd * g.z + bb.z, (v[c].w - mean) * rstd * g.w + bb.w));
+    }
+  }
+}
+
+// LayerNorm backward.  dh = dh_a (+ dh_b).  Outputs dy (gradient of the pre-LN sum: goes to the residual
+// branch) and dt = dropout-mask(dy) (gradient of the dense output; same buffer as dy when p == 0), plus
+// column sums: dgamma, dbeta, dbias (= colsum dt).
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dh_a, const bf16* dh_b, const bf16* y, const float* mean_i,
+                                                     const float* rstd_i, const float* gamma, bf16* dy, bf16* dt,
+                                                     float* dgamma, float* dbeta, float* dbias, int M, int H, int rows_per_wave,
+                                                     Drop dr) {
+  __shared__ float red[3][4][64 * 4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r0 = (blockIdx.x * 4 + wv) * rows_per_wave, r1 = min(M, r0 + rows_per_wave);
+  float4 ag[MAXC], ab[MAXC], abias[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) ag[c] = ab[c] = abias[c] = make_float4(0, 0, 0, 0);
+  for (int row = r0; row < r1; ++row) {
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float4 g[MAXC], xh[MAXC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int col = lane * 4 + c * 256;
+      if (col < H) {
+        float4 d = ld4(dh_a + (size_t)row * H + col);
+        if (dh_b) {
+          const float4 e = ld4(dh_b + (size_t)row * H + col);
+          d = make_float4(d.x + e.x, d.y + e.y, d.z + e.z, d.w + e.w);
+        }
+        const float4 yy = ld4(y + (size_t)row * H + col), gm = ld4(gamma + col);
+        xh[c] = make_float4((yy.x - mean) * rstd, (yy.y - mean) * rstd, (yy.z - mean) * rstd, (yy.w - mean) * rstd);
+        ag[c].x += d.x * xh[c].x; ag[c].y += d.y * xh[c].y; ag[c].z += d.z * xh[c].z; ag[c].w += d.w * xh[c].w;
+        ab[c].x += d.x; ab[c].y += d.y; ab[c].z += d.z; ab[c].w += d.w;
+        g[c] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+        s1 += g[c].x + g[c].y + g[c].z + g[c].w;
+        s2 += g[c].x * xh[c].x + g[c].y * xh[c].y + g[c].z * xh[c].z + g[c].w * xh[c].w;
+      }
+    }
+    s1 = wave_sum(s1) / H; s2 = wave_sum(s2) / H;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int col = lane * 4 + c * 256;
+      if (col < H) {
+        const float4 o = make_float4(rstd * (g[c].x - s1 - xh[c].x * s2), rstd * (g[c].y - s1 - xh[c].y * s2),
+                                     rstd * (g[c].z - s1 - xh[c].z * s2), rstd * (g[c].w - s1 - xh[c].w * s2));
+        st4(dy + (size_t)row * H + col, o);
+        float4 od = o;
+        if (dr.thresh) {
+          od = drop4(o, dr, (unsigned long long)row * H + col);
+          st4(dt + (size_t)row * H + col, od);
+        }
+        // the dense-output gradient the GEMMs consume is the bf16-rounded value
+        abias[c].x += bf2f(f2bf(od.x)); abias[c].y += bf2f(f2bf(od.y)); abias[c].z += bf2f(f2bf(od.z)); abias[c].w += bf2f(f2bf(od.w));
+      }
+    }
+  }
+  // cross-wave reduction through LDS, then one atomic per column per block
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int col = lane * 4 + c * 256;
+    if (c * 256 >= H) break;   // uniform
+    __syncthreads();
+    float4* r0p = reinterpret_cast<float4*>(&red[0][wv][lane * 4]);
+    float4* r1p = reinterpret_cast<float4*>(&red[1][wv][lane * 4]);
+    float4* r2p = reinterpret_cast<float4*>(&red[2][wv][lane * 4]);
+    *r0p = ag[c]; *r1p = ab[c]; *r2p = abias[c];
+    __syncthreads();
+    if (wv < 3 && col < H) {
+      float* dst = wv == 0 ? dgamma : (wv == 1 ? dbeta : dbias);
+      if (dst) {
+        float4 a = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 b = *reinterpret_cast<const float4*>(&red[wv][k][lane * 4]);
+          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        atomicAdd(dst + col, a.x); atomicAdd(dst + col + 1, a.y); atomicAdd(dst + col + 2, a.z); atomicAdd(dst + col + 3, a.w);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- column sums of a bf16 matrix
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* x, int ld, float* out, int M, int N, int rows_per_block) {
+  __shared__ float red[4][64 * 8];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int col = blockIdx.x * 512 + lane * 8;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (col < N) {
+    for (int row = r0 + wv; row < r1; row += 4) {
+      const bf8 v = *reinterpret_cast<const bf8*>(x + (size_t)row * ld + col);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[wv][lane * 8 + j] = acc[j];
+  __syncthreads();
+  if (wv == 0 && col < N) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float s = red[0][lane * 8 + j] + red[1][lane * 8 + j] + red[2][lane * 8 + j] + red[3][lane * 8 + j];
+      if (col + j < N) atomicAdd(out + col + j, s);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- row L2 normalisation
+// out[r, col_off + c] = x[r,c] / max(||x_r||, eps); writes f32 and/or bf16 copies; inv_norm[r] saved.
+template <typename TIN>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const TIN* x, int ldx, float* out_f, bf16* out_b, int ldo, int col_off,
+                                                         float* inv_norm, int R, int D, float eps, float post_scale) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= R) return;
+  float ss = 0.f;
+  for (int col = lane * 4; col < D; col += 256) {
+    const float4 v = ld4(x + (size_t)row * ldx + col);
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  const float inv = 1.0f / fmaxf(sqrtf(ss), eps);
+  if (lane == 0 && inv_norm) inv_norm[row] = inv;
+  const float sc = inv * post_scale;
+  for (int col = lane * 4; col < D; col += 256) {
+    const float4 v = ld4(x + (size_t)row * ldx + col);
+    const float4 o = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
+    if (out_f) st4(out_f + (size_t)row * ldo + col_off + col, o);
+    if (out_b) st4(out_b + (size_t)row * ldo + col_off + col, o);
+  }
+}
+
+// dx = (dxh - xh * (xh . dxh)) * inv,  xh = x * inv ;  dxh read from dxh[r, col_off + c] * pre_scale
+template <typename TX>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const TX* x, int ldx, const float* inv_norm, const float* dxh, int ldd,
+                                                         int col_off, float* dx, int lddx, int R, int D, float pre_scale, int accumulate) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= R) return;
+  const float inv = inv_norm[row];
+  float dot = 0.f;
+  for (int col = lane * 4; col < D; col += 256) {
+    const float4 v = ld4(x + (size_t)row * ldx + col);
+    const float4 g = ld4(dxh + (size_t)row * ldd + col_off + col);
+    dot += (v.x * g.x + v.y * g.y + v.z * g.z + v.w * g.w);
+  }
+  dot = wave_sum(dot) * inv * pre_scale;
+  for (int col = lane * 4; col < D; col += 256) {
+    const float4 v = ld4(x + (size_t)row * ldx + col);
+    const float4 g = ld4(dxh + (size_t)row * ldd + col_off + col);
+    float4 o = make_float4((g.x * pre_scale - v.x * inv * dot) * inv, (g.y * pre_scale - v.y * inv * dot) * inv,
+                           (g.z * pre_scale - v.z * inv * dot) * inv, (g.w * pre_scale - v.w * inv * dot) * inv);
+    if (accumulate) {
+      const float4 old = ld4(dx + (size_t)row * lddx + col);
+      o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+    }
+    st4(dx + (size_t)row * lddx + col, o);
+  }
+}
+
+// ================================================================= C-ABI
+#define ROWS_GRID(M) dim3(((M) + 3) / 4)
+
+extern "C" int mmsim_embed_ln_fwd(const long long* ids, const long long* token_types, const float* word, const float* pos,
+                                  const float* type, const float* gamma, const float* beta, void* out, int B, int S, int H,
+                                  float eps, float dropout_p, unsigned long long seed, unsigned int stream_id, void* stream) {
+  MMSIM_REQUIRE(ids && word && pos && type && gamma && beta && out, "embed_ln_fwd: null operand");
+  MMSIM_REQUIRE(H % 4 == 0 && H <= 256 * MAXC, "embed_ln_fwd: H must be a multiple of 4 and <= 2048");
+  const int M = B * S;
+  hipLaunchKernelGGL(embed_ln_fwd_kernel, ROWS_GRID(M), dim3(256), 0, (hipStream_t)stream, (const int64_t*)ids,
+                     (const int64_t*)token_types, word, pos, type, gamma, beta, (bf16*)out, M, S, H, eps,
+                     make_drop(dropout_p, seed, stream_id));
+  return mmsim_check_launch("embed_ln_fwd");
+}
+
+extern "C" int mmsim_embed_ln_bwd(const void* dout, const long long* ids, const long long* token_types, const float* word,
+                                  const float* pos, const float* type, const float* gamma, float* dword, float* dpos,
+                                  float* dtype, float* dgamma, float* dbeta, int B, int S, int H, float eps, float dropout_p,
+                                  unsigned long long seed, unsigned int stream_id, void* stream) {
+  MMSIM_REQUIRE(dout && ids && word && dword && dpos && dtype && dgamma && dbeta, "embed_ln_bwd: null operand");
+  MMSIM_REQUIRE(H % 4 == 0 && H <= 256 * MAXC, "embed_ln_bwd: H must be a multiple of 4 and <= 2048");
+  const int bchunk = B >= 64 ? 16 : (B >= 8 ? 4 : 1);
+  const int nw = S * ((B + bchunk - 1) / bchunk);
+  hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout,
+                     (const int64_t*)ids, (const int64_t*)token_types, word, pos, type, gamma, dword, dpos, dtype, dgamma,
+                     dbeta, B, S, H, eps, bchunk, make_drop(dropout_p, seed, stream_id));
+  return mmsim_check_launch("embed_ln_bwd");
+}
+
+extern "C" int mmsim_add_ln_fwd(const void* t, const void* resid, const float* gamma, const float* beta, void* y, void* h,
+                                float* mean, float* rstd, int M, int H, float eps, float dropout_p,
+                                unsigned long long seed, unsigned int stream_id, void* stream) {
+  MMSIM_REQUIRE(t && resid && gamma && beta && y && h && mean && rstd, "add_ln_fwd: null operand");
+  MMSIM_REQUIRE(H % 4 == 0 && H <= 256 * MAXC, "add_ln_fwd: H must be a multiple of 4 and <= 2048");
+  hipLaunchKernelGGL(add_ln_fwd_kernel, ROWS_GRID(M), dim3(256), 0, (hipStream_t)stream, (const bf16*)t, (const bf16*)resid,
+                     gamma, beta, (bf16*)y, (bf16*)h, mean, rstd, M, H, eps, make_drop(dropout_p, seed, stream_id));
+  return mmsim_check_launch("add_ln_fwd");
+}
+
+extern "C" int mmsim_ln_bwd(const void* dh_a, const void* dh_b, const void* y, const float* mean, const float* rstd,
+                            const float* gamma, void* dy, void* dt, float* dgamma, float* dbeta, float* dbias, int M, int H,
+                            float dropout_p, unsigned long long seed, unsigned int stream_id, void* stream) {
+  MMSIM_REQUIRE(dh_a && y && mean && rstd && gamma && dy && dgamma && dbeta, "ln_bwd: null operand");
+  MMSIM_REQUIRE(H % 4 == 0 && H <= 256 * MAXC, "ln_bwd: H must be a multiple of 4 and <= 2048");
+  MMSIM_REQUIRE(dropout_p == 0.f || dt, "ln_bwd: dropout needs a separate dt buffer");
+  int rpw = (M + 2047) / 2048;   // ~512 blocks of 4 waves
+  if (rpw < 1) rpw = 1;
+  const int nblk = (M + 4 * rpw - 1) / (4 * rpw);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16*)dh_a, (const bf16*)dh_b,
+                     (const bf16*)y, mean, rstd, gamma, (bf16*)dy, (bf16*)dt, dgamma, dbeta, dbias, M, H, rpw,
+                     make_drop(dropout_p, seed, stream_id));
+  return mmsim_check_launch("ln_bwd");
+}
+
+extern "C" int mmsim_colsum_bf16(const void* x, int ld, float* out, int M, int N, void* stream) {
+  MMSIM_REQUIRE(x && out && M > 0 && N > 0, "colsum: bad arguments");
+  MMSIM_REQUIRE(ld % 8 == 0 && ld >= ((N + 7) & ~7), "colsum: ld must be a multiple of 8 covering N rounded up to 8");
+  const int rpb = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)x, ld, out, M, N, rpb);
+  return mmsim_check_launch("colsum");
+}
+
+extern "C" int mmsim_l2norm_fwd(const void* x, int x_is_bf16, int ldx, float* out_f32, void* out_bf16, int ldo, int col_off,
+                                float* inv_norm, int R, int D, float eps, float post_scale, void* stream) {
+  MMSIM_REQUIRE(x && (out_f32 || out_bf16) && R > 0 && D > 0, "l2norm_fwd: bad arguments");
+  MMSIM_REQUIRE(D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && col_off % 4 == 0, "l2norm_fwd: D, ld, col_off must be multiples of 4");
+  if (x_is_bf16)
+    hipLaunchKernelGGL((l2norm_fwd_kernel<bf16>), ROWS_GRID(R), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, out_f32,
+                       (bf16*)out_bf16, ldo, col_off, inv_norm, R, D, eps, post_scale);
+  else
+    hipLaunchKernelGGL((l2norm_fwd_kernel<float>), ROWS_GRID(R), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, out_f32,
+                       (bf16*)out_bf16, ldo, col_off, inv_norm, R, D, eps, post_scale);
+  return mmsim_check_launch("l2norm_fwd");
+}
+
+extern "C" int mmsim_l2norm_bwd(const void* x, int x_is_bf16, int ldx, const float* inv_norm, const float* dxh, int ldd,
+                                int col_off, float* dx, int lddx, int R, int D, float pre_scale, int accumulate,
+                                void* stream) {
+  MMSIM_REQUIRE(x && inv_norm && dxh && dx && R > 0 && D > 0, "l2norm_bwd: bad arguments");
+  MMSIM_REQUIRE(D % 4 == 0 && ldx % 4 == 0 && ldd % 4 == 0 && lddx % 4 == 0 && col_off % 4 == 0, "l2norm_bwd: multiples of 4 required");
+  if (x_is_bf16)
+    hipLaunchKernelGGL((l2norm_bwd_kernel<bf16>), ROWS_GRID(R), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, inv_norm,
+                       dxh, ldd, col_off, dx, lddx, R, D, pre_scale, accumulate);
+  else
+    hipLaunchKernelGGL((l2norm_bwd_kernel<float>), ROWS_GRID(R), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx,
+                       inv_norm, dxh, ldd, col_off, dx, lddx, R, D, pre_scale, accumulate);
+  return mmsim_check_launch("l2norm_bwd");
+}

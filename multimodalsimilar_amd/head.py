@@ -1,0 +1,223 @@
+"""ArcFace margin head and the two-tower glue on the HIP kernels.
+
+ArcMarginProduct mirrors /root/reference/arcface.py:17-67 (same constructor, attributes, forward /
+forward_test / update_m) and adds ``forward_loss`` -- the fused path the training entry point uses:
+normalise -> bf16 MFMA cosine GEMM -> margin + scaled cross-entropy + argmax + dcos in one pass over the
+cosines (no logits / softmax / one-hot tensors), then the two backward GEMMs and the normalise backward.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .flat import FlatBuffer
+from ._lib import MmsimError
+
+
+def _margin_consts(m):
+    return math.cos(m), math.sin(m), math.cos(math.pi - m), math.sin(math.pi - m) * m
+
+
+class ArcMarginProduct(nn.Module):
+    def __init__(self, in_feature=128, out_feature=10575, s=64.0, m=0.40, easy_margin=False):
+        super().__init__()
+        if in_feature % 8:
+            raise ValueError("ArcMarginProduct: in_feature must be a multiple of 8 for the bf16 MFMA kernels")
+        self.in_feature = in_feature
+        self.out_feature = out_feature
+        self.s = s
+        self.m = m
+        self._flat = FlatBuffer([("weight", (out_feature, in_feature))], device="cpu")
+        w = self._flat.view("weight")
+        nn.init.xavier_uniform_(w)                                                   # arcface.py:25
+        self.weight = nn.Parameter(w)
+        self.easy_margin = easy_margin
+        self.cos_m, self.sin_m, self.th, self.mm = _margin_consts(m)                 # arcface.py:28-33
+        self._scratch = {}
+        self.grad_ready_hook = None
+
+    def update_m(self, delta):                                                       # arcface.py:35-42
+        updated_m = self.m + delta
+        if updated_m >= 1e-6 and updated_m <= 1.0:
+            self.m = updated_m
+            self.cos_m, self.sin_m, self.th, self.mm = _margin_consts(self.m)
+
+    # ---- flat-buffer plumbing (same contract as the towers)
+    def _apply(self, fn, recurse=True):
+        self._flat.apply_(fn)
+        self.weight.data = self._flat.view("weight")
+        self.weight.grad = None
+        self._scratch = {}
+        return self
+
+    def flat_buffers(self):
+        return [self._flat]
+
+    def _bind_grads(self):
+        fl = self._flat
+        if fl.grad is None or fl.grad.device != fl.master.device:
+            fl.grad = torch.zeros_like(fl.master)
+        g = fl.gview("weight")
+        if self.weight.grad is None or self.weight.grad.data_ptr() != g.data_ptr():
+            self.weight.grad = g
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_scratch"] = {}
+        st["grad_ready_hook"] = None
+        return st
+
+    def _buf(self, name, shape, dtype, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self._scratch.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.weight.device)
+            self._scratch[key] = t
+        return t
+
+    # ---- kernels
+    def _cosines(self, x):
+        """x [B,D] f32 -> (cos f32 [B, ldc] view [:, :C], saved state)."""
+        if not x.is_cuda:
+            raise MmsimError("ArcMarginProduct: inputs must be on the GPU; the HIP path has no CPU fallback")
+        if x.dim() != 2 or x.shape[1] != self.in_feature:
+            raise ValueError(f"ArcMarginProduct: expected x [B, {self.in_feature}], got {tuple(x.shape)}")
+        B, D, C = x.shape[0], self.in_feature, self.out_feature
+        x = x.contiguous().float()
+        ldc = ops.round_up(C, 8)
+        wh = self._buf("wh", (C, D), torch.bfloat16)
+        inv_w = self._buf("inv_w", (C,), torch.float32)
+        xh = self._buf("xh", (B, D), torch.bfloat16)
+        inv_x = self._buf("inv_x", (B,), torch.float32)
+        cos = self._buf("cos", (B, ldc), torch.float32, zero=True)
+        ops.l2norm_fwd(self.weight.detach(), None, wh, 0, inv_w)                     # F.normalize(self.weight)
+        ops.l2norm_fwd(x, None, xh, 0, inv_x)                                        # F.normalize(x)
+        ops.gemm(xh, wh, cos[:, :C])                                                 # F.linear  (arcface.py:47)
+        return cos, dict(x=x, xh=xh, wh=wh, inv_x=inv_x, inv_w=inv_w, B=B, ldc=ldc)
+
+    def _backward_from_dcos(self, st, dcos):
+        """dcos bf16 [B, ldc] (pad zero) -> dx f32 [B,D]; accumulates into weight.grad."""
+        B, D, C, ldc = st["B"], self.in_feature, self.out_feature, st["ldc"]
+        self._bind_grads()
+        dxh = self._buf("dxh", (B, D), torch.float32)
+        dwh = self._buf("dwh", (C, D), torch.float32)
+        dx = torch.empty((B, D), dtype=torch.float32, device=dcos.device)
+        ops.gemm(dcos[:, :C], st["wh"], dxh, b_kmajor=False)                         # dxh = dcos @ Wh
+        ops.gemm(dcos[:, :C], st["xh"], dwh, trans_a=True, b_kmajor=False)           # dWh = dcos^T @ xh
+        ops.l2norm_bwd(st["x"], st["inv_x"], dxh, 0, dx)
+        ops.l2norm_bwd(self.weight.detach(), st["inv_w"], dwh, 0, self._flat.gview("weight"), accumulate=True)
+        if self.grad_ready_hook:
+            self.grad_ready_hook(self._flat, 0, self._flat.total)
+        return dx
+
+    def _err_flag(self):
+        return self._buf("err", (1,), torch.int32, zero=True)
+
+    def check_labels(self):
+        """Raise if any label seen since the last check was outside [0, out_feature) (reference: scatter_ raises)."""
+        f = self._scratch.get(("err", (1,), torch.int32))
+        if f is not None and int(f.item()) != 0:
+            f.zero_()
+            raise IndexError("ArcMarginProduct: label out of range [0, out_feature)")
+
+    # ---- public API
+    def forward(self, x, label):                                                     # arcface.py:45-63
+        return _ArcLogitsFn.apply(x, self.weight, self, label)
+
+    def forward_test(self, x):                                                       # arcface.py:65-67
+        with torch.no_grad():
+            cos, _ = self._cosines(x)
+        return cos[:, :self.out_feature].clone()
+
+    def forward_loss(self, x, label, want_argmax=True):
+        """Fused margin + scale + mean cross-entropy.  Returns (loss scalar, argmax int64 [B])."""
+        return _ArcLossFn.apply(x, self.weight, self, label)
+
+
+class _ArcLogitsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, mod, label):
+        cos, st = mod._cosines(x)
+        C = mod.out_feature
+        label = label.contiguous()
+        logits = cos.clone()
+        ops.lib.arcface_margin(logits.data_ptr(), st["ldc"], label.data_ptr(), st["B"], C, mod.s, mod.m,
+                               int(mod.easy_margin), mod._err_flag().data_ptr(), ops._stream())
+        mod.check_labels()   # API path keeps the reference's eager error (costs one host sync)
+        ctx.mod, ctx.st, ctx.label = mod, st, label
+        ctx.cos = cos.clone()
+        return logits[:, :C]
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        mod, st = ctx.mod, ctx.st
+        C = mod.out_feature
+        dlogits = dlogits.contiguous().float()
+        dcos = mod._buf("dcos", (st["B"], st["ldc"]), torch.bfloat16)
+        ops.lib.arcface_dlogits_to_dcos(dlogits.data_ptr(), dlogits.stride(0), ctx.cos.data_ptr(), st["ldc"],
+                                        ctx.label.data_ptr(), dcos.data_ptr(), st["B"], C, mod.s, mod.m,
+                                        int(mod.easy_margin), ops._stream())
+        dx = mod._backward_from_dcos(st, dcos)
+        return dx, None, None, None
+
+
+class _ArcLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, mod, label):
+        cos, st = mod._cosines(x)
+        B, C = st["B"], mod.out_feature
+        label = label.contiguous()
+        loss_b = torch.empty(B, dtype=torch.float32, device=x.device)
+        argmax = torch.empty(B, dtype=torch.int64, device=x.device)
+        need_grad = x.requires_grad or weight.requires_grad
+        dcos = mod._buf("dcos", (B, st["ldc"]), torch.bfloat16) if need_grad else None
+        ops.lib.arcface_ce(cos.data_ptr(), st["ldc"], label.data_ptr(), loss_b.data_ptr(), argmax.data_ptr(),
+                           None if dcos is None else dcos.data_ptr(), B, C, mod.s, mod.m, int(mod.easy_margin),
+                           1.0 / B, mod._err_flag().data_ptr(), ops._stream())
+        ctx.mod, ctx.st, ctx.dcos = mod, st, dcos
+        ctx.mark_non_differentiable(argmax)
+        return loss_b.mean(), argmax
+
+    @staticmethod
+    def backward(ctx, dloss, _dargmax):
+        dcos = ctx.dcos
+        dcos.mul_(dloss.to(dcos.dtype))      # chain rule for a non-unit upstream gradient (bf16(1.0) is exact)
+        dx = ctx.mod._backward_from_dcos(ctx.st, dcos)
+        return dx, None, None, None
+
+
+class _GlueFn(torch.autograd.Function):
+    """final = cat(normalize(img), normalize(txt), dim=1)   (multimodal_classifier.py:54-56)"""
+
+    @staticmethod
+    def forward(ctx, img, txt):
+        img = img.contiguous().float()
+        txt = txt.contiguous().float()
+        B, Di = img.shape
+        Dt = txt.shape[1]
+        if Di % 4 or Dt % 4:
+            raise ValueError("two-tower glue: embedding widths must be multiples of 4")
+        final = torch.empty((B, Di + Dt), dtype=torch.float32, device=img.device)
+        inv_i = torch.empty(B, dtype=torch.float32, device=img.device)
+        inv_t = torch.empty(B, dtype=torch.float32, device=img.device)
+        ops.l2norm_fwd(img, final, None, 0, inv_i)
+        ops.l2norm_fwd(txt, final, None, Di, inv_t)
+        ctx.save_for_backward(img, txt, inv_i, inv_t)
+        return final
+
+    @staticmethod
+    def backward(ctx, dfinal):
+        img, txt, inv_i, inv_t = ctx.saved_tensors
+        dfinal = dfinal.contiguous().float()
+        dimg = torch.empty_like(img)
+        dtxt = torch.empty_like(txt)
+        ops.l2norm_bwd(img, inv_i, dfinal, 0, dimg)
+        ops.l2norm_bwd(txt, inv_t, dfinal, img.shape[1], dtxt)
+        return dimg, dtxt
+
+
+def glue_concat(img_emb, txt_emb):
+    if not (img_emb.is_cuda and txt_emb.is_cuda):
+        raise MmsimError("glue_concat: embeddings must be on the GPU; the HIP path has no CPU fallback")
+    return _GlueFn.apply(img_emb, txt_emb)

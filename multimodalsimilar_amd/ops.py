@@ -1,0 +1,200 @@
+"""Tensor-level wrappers over the C ABI (include/mmsim_hip.h).
+
+Every wrapper validates dtype / device / contiguity / shape in Python and raises BEFORE anything is
+launched, then passes raw device pointers and the current HIP stream to libmmsim_hip.so.
+torch is used for memory and streams only.
+"""
+import torch
+
+from ._lib import lib, MmsimError
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+I64 = torch.int64
+
+EPI_NONE, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_ADD, EPI_TANH = 0, 1, 2, 3, 4
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype, name, dims=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise MmsimError(f"{name}: tensor must live on the GPU (got {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if dims is not None and t.dim() != dims:
+        raise ValueError(f"{name}: expected {dims} dims, got shape {tuple(t.shape)}")
+    if t.dim() >= 1 and t.numel() > 0 and t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost dimension must be contiguous")
+    return t
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ld(t):
+    return t.stride(0) if t.dim() == 2 and t.shape[0] > 1 else t.shape[-1]
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def alloc_2d(rows, cols, dtype, device, mult=8, zero=False):
+    """[rows, cols] view of a buffer whose leading dimension is cols rounded up to `mult` (pad zeroed if asked)."""
+    ld = round_up(cols, mult)
+    buf = (torch.zeros if zero or ld != cols else torch.empty)((rows, ld), dtype=dtype, device=device)
+    return buf[:, :cols] if ld != cols else buf
+
+
+def gemm(a, b, c, *, trans_a=False, b_kmajor=True, bias=None, epilogue=EPI_NONE, aux_in=None, aux_out=None,
+         alpha=1.0, split_k=1, accumulate=False):
+    """c[M,N] = alpha * op(a) @ op(b) (+ bias) with fused epilogue; see mmsim_gemm_bf16."""
+    _chk(a, BF16, "gemm.a", 2); _chk(b, BF16, "gemm.b", 2)
+    if c.dtype not in (BF16, F32):
+        raise TypeError("gemm.c: bf16 or f32 output")
+    _chk(c, c.dtype, "gemm.c", 2)
+    M, N = c.shape
+    K = a.shape[0] if trans_a else a.shape[1]
+    am = a.shape[1] if trans_a else a.shape[0]
+    bk, bn = (b.shape[1], b.shape[0]) if b_kmajor else (b.shape[0], b.shape[1])
+    if am != M or bn != N or bk != K:
+        raise ValueError(f"gemm: shape mismatch a{tuple(a.shape)} b{tuple(b.shape)} c{tuple(c.shape)} "
+                         f"trans_a={trans_a} b_kmajor={b_kmajor}")
+    if bias is not None:
+        _chk(bias, F32, "gemm.bias", 1)
+        if bias.shape[0] != N:
+            raise ValueError("gemm.bias: length must equal N")
+    ld_aux = 0
+    for t, nm in ((aux_in, "gemm.aux_in"), (aux_out, "gemm.aux_out")):
+        if t is not None:
+            _chk(t, BF16, nm, 2)
+            if tuple(t.shape) != (M, N):
+                raise ValueError(f"{nm}: shape must equal the output shape")
+            ld_aux = _ld(t)
+    lib.gemm_bf16(int(trans_a), int(b_kmajor), M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(c), _ld(c),
+                  int(c.dtype == F32), _p(bias), epilogue, _p(aux_in), _p(aux_out), ld_aux, float(alpha), split_k,
+                  int(accumulate), _stream())
+    return c
+
+
+def pick_split_k(M, N, K):
+    """wgrad-style products have few output tiles and a long reduction: split K until ~2 waves of blocks."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    s = 1
+    while tiles * s < 512 and K // (s * 2) >= 512:
+        s *= 2
+    return s
+
+
+def attn_fwd(qkv, mask, ctx, lse, B, S, heads, H, dropout_p=0.0, seed=0, stream_id=0):
+    _chk(qkv, BF16, "attn.qkv", 2); _chk(ctx, BF16, "attn.ctx", 2); _chk(lse, F32, "attn.lse")
+    if mask is not None:
+        _chk(mask, I64, "attn.mask", 2)
+    if qkv.shape[0] != B * S or ctx.shape[0] != B * S or lse.numel() < B * heads * S:
+        raise ValueError("attn_fwd: buffer shapes do not match B*S")
+    lib.attn_fwd(_p(qkv), _ld(qkv), _p(mask), _p(ctx), _ld(ctx), _p(lse), B, S, heads, H, float(dropout_p), seed,
+                 stream_id, _stream())
+
+
+def attn_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, heads, H, dropout_p=0.0, seed=0, stream_id=0):
+    for t, n in ((qkv, "qkv"), (ctx, "ctx"), (dctx, "dctx"), (dqkv, "dqkv")):
+        _chk(t, BF16, "attn_bwd." + n, 2)
+    _chk(lse, F32, "attn_bwd.lse")
+    if _ld(dqkv) != _ld(qkv) or _ld(dctx) != _ld(ctx):
+        raise ValueError("attn_bwd: gradient buffers must share the leading dimensions of their primals")
+    lib.attn_bwd(_p(qkv), _ld(qkv), _p(mask), _p(ctx), _p(dctx), _ld(ctx), _p(lse), _p(dqkv), B, S, heads, H,
+                 float(dropout_p), seed, stream_id, _stream())
+
+
+def embed_ln_fwd(ids, tts, word, pos, typ, gamma, beta, out, B, S, H, eps, dropout_p=0.0, seed=0, stream_id=0):
+    _chk(ids, I64, "embed.ids"); _chk(out, BF16, "embed.out", 2)
+    for t, n in ((word, "word"), (pos, "pos"), (typ, "type"), (gamma, "gamma"), (beta, "beta")):
+        _chk(t, F32, "embed." + n)
+    if tts is not None:
+        _chk(tts, I64, "embed.token_types")
+    if ids.numel() != B * S or pos.shape[0] < S:
+        raise ValueError("embed_ln_fwd: ids must hold B*S tokens and the position table must cover S")
+    lib.embed_ln_fwd(_p(ids), _p(tts), _p(word), _p(pos), _p(typ), _p(gamma), _p(beta), _p(out), B, S, H, eps,
+                     float(dropout_p), seed, stream_id, _stream())
+
+
+def embed_ln_bwd(dout, ids, tts, word, pos, typ, gamma, dword, dpos, dtype_, dgamma, dbeta, B, S, H, eps,
+                 dropout_p=0.0, seed=0, stream_id=0):
+    _chk(dout, BF16, "embed_bwd.dout", 2)
+    for t, n in ((dword, "dword"), (dpos, "dpos"), (dtype_, "dtype"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+        _chk(t, F32, "embed_bwd." + n)
+    lib.embed_ln_bwd(_p(dout), _p(ids), _p(tts), _p(word), _p(pos), _p(typ), _p(gamma), _p(dword), _p(dpos),
+                     _p(dtype_), _p(dgamma), _p(dbeta), B, S, H, eps, float(dropout_p), seed, stream_id, _stream())
+
+
+def add_ln_fwd(t, resid, gamma, beta, y, h, mean, rstd, eps, dropout_p=0.0, seed=0, stream_id=0):
+    for x, n in ((t, "t"), (resid, "resid"), (y, "y"), (h, "h")):
+        _chk(x, BF16, "add_ln." + n, 2)
+        if not x.is_contiguous() or x.shape != t.shape:
+            raise ValueError(f"add_ln.{n}: must be contiguous [M,H]")
+    M, H = t.shape
+    lib.add_ln_fwd(_p(t), _p(resid), _p(gamma), _p(beta), _p(y), _p(h), _p(mean), _p(rstd), M, H, eps,
+                   float(dropout_p), seed, stream_id, _stream())
+
+
+def ln_bwd(dh_a, dh_b, y, mean, rstd, gamma, dy, dt, dgamma, dbeta, dbias, dropout_p=0.0, seed=0, stream_id=0):
+    for x, n in ((dh_a, "dh_a"), (y, "y"), (dy, "dy")):
+        _chk(x, BF16, "ln_bwd." + n, 2)
+        if not x.is_contiguous():
+            raise ValueError(f"ln_bwd.{n}: must be contiguous")
+    M, H = y.shape
+    lib.ln_bwd(_p(dh_a), _p(dh_b), _p(y), _p(mean), _p(rstd), _p(gamma), _p(dy), _p(dt), _p(dgamma), _p(dbeta),
+               _p(dbias), M, H, float(dropout_p), seed, stream_id, _stream())
+
+
+def colsum(x, out):
+    _chk(x, BF16, "colsum.x", 2); _chk(out, F32, "colsum.out", 1)
+    lib.colsum_bf16(_p(x), _ld(x), _p(out), x.shape[0], x.shape[1], _stream())
+
+
+def l2norm_fwd(x, out_f32, out_bf16, col_off, inv_norm, eps=1e-12, post_scale=1.0):
+    if x.dtype not in (BF16, F32):
+        raise TypeError("l2norm_fwd.x: bf16 or f32")
+    _chk(x, x.dtype, "l2norm_fwd.x", 2)
+    o = out_f32 if out_f32 is not None else out_bf16
+    R, D = x.shape
+    lib.l2norm_fwd(_p(x), int(x.dtype == BF16), _ld(x), _p(out_f32), _p(out_bf16), _ld(o), col_off, _p(inv_norm), R, D,
+                   eps, float(post_scale), _stream())
+
+
+def l2norm_bwd(x, inv_norm, dxh, col_off, dx, pre_scale=1.0, accumulate=False):
+    _chk(x, x.dtype, "l2norm_bwd.x", 2); _chk(dxh, F32, "l2norm_bwd.dxh", 2); _chk(dx, F32, "l2norm_bwd.dx", 2)
+    R, D = x.shape
+    lib.l2norm_bwd(_p(x), int(x.dtype == BF16), _ld(x), _p(inv_norm), _p(dxh), _ld(dxh), col_off, _p(dx), _ld(dx), R, D,
+                   float(pre_scale), int(accumulate), _stream())
+
+
+def cast_to_bf16(x, y):
+    _chk(x, F32, "cast.x"); _chk(y, BF16, "cast.y")
+    if x.numel() != y.numel() or not x.is_contiguous() or not y.is_contiguous():
+        raise ValueError("cast: contiguous tensors of equal size")
+    lib.cast_f32_to_bf16(_p(x), _p(y), x.numel(), _stream())
+
+
+def cast_to_f32(x, y):
+    _chk(x, BF16, "cast.x"); _chk(y, F32, "cast.y")
+    if x.numel() != y.numel() or not x.is_contiguous() or not y.is_contiguous():
+        raise ValueError("cast: contiguous tensors of equal size")
+    lib.cast_bf16_to_f32(_p(x), _p(y), x.numel(), _stream())
+
+
+def adamw_step(p, g, m, v, shadow, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, F32, "adamw." + n, 1)
+        if t.numel() != p.numel():
+            raise ValueError("adamw: buffers must have equal length")
+    if shadow is not None:
+        _chk(shadow, BF16, "adamw.shadow", 1)
+    lib.adamw_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                   float(weight_decay), int(step), float(grad_scale), _stream())

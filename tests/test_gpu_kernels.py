@@ -1,0 +1,260 @@
+"""Per-kernel parity on the MI355X: each HIP kernel (called through the C ABI) against a plain fp32 PyTorch
+reference of the same op on the same (bf16-rounded) inputs.  Tolerances: bf16 outputs 1e-2 of the output scale,
+fp32 outputs 2e-3 (bf16 products, fp32 accumulation) -- BASELINE.json north_star: 1e-3 fp32 / 1e-2 bf16."""
+import math
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from multimodalsimilar_amd import ops
+    return ops
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def rnd(*s, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*s, generator=g) * scale).to(DEV)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 136, 72), (1000, 40, 128), (8, 1000, 768),
+                                   (513, 257, 1032)])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_layouts(M, N, K, layout):
+    ops = _ops()
+    if layout == "tn" and M % 8:
+        M = (M + 7) // 8 * 8
+    if layout != "nt" and N % 8:
+        N = (N + 7) // 8 * 8
+    a = rnd(M, K, seed=1).bfloat16()
+    b = rnd(N, K, seed=2).bfloat16()
+    ref = a.float() @ b.float().t()
+    if layout == "nt":
+        A, Bm, kw = a, b, dict()
+    elif layout == "nn":
+        A, Bm, kw = a, b.t().contiguous(), dict(b_kmajor=False)
+    else:
+        A, Bm, kw = a.t().contiguous(), b.t().contiguous(), dict(trans_a=True, b_kmajor=False)
+    c = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(A, Bm, c, **kw)
+    assert relerr(c, ref) < 2e-3
+    cb = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A, Bm, cb, **kw)
+    assert relerr(cb, ref) < 1e-2
+
+
+def test_gemm_epilogues_and_splitk():
+    ops = _ops()
+    M, N, K = 384, 256, 320
+    a = rnd(M, K, seed=3).bfloat16(); b = rnd(N, K, seed=4, scale=0.1).bfloat16()
+    bias = rnd(N, seed=5)
+    pre = a.float() @ b.float().t() + bias
+    # bias + GELU with pre-activation side output
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); aux = torch.empty_like(c)
+    ops.gemm(a, b, c, bias=bias, epilogue=ops.EPI_GELU, aux_out=aux)
+    assert relerr(aux, pre) < 1e-2 and relerr(c, F.gelu(pre)) < 1e-2
+    # tanh, f32 out
+    cf = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(a, b, cf, bias=bias, epilogue=ops.EPI_TANH)
+    assert (cf - torch.tanh(pre)).abs().max() < 5e-3
+    # multiply by gelu'(aux_in)
+    x = aux.float().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    ops.gemm(a, b, c, epilogue=ops.EPI_MUL_GELU_GRAD, aux_in=aux)
+    assert relerr(c, (pre - bias) * x.grad) < 1e-2
+    # residual add
+    r = rnd(M, N, seed=6).bfloat16()
+    ops.gemm(a, b, c, epilogue=ops.EPI_ADD, aux_in=r)
+    assert relerr(c, pre - bias + r.float()) < 1e-2
+    # split-K atomic accumulation on top of existing contents, and plain accumulate
+    at = a.t().contiguous()        # [K, M] -> product over K as the slow index
+    bt = b.t().contiguous()
+    base = rnd(M, N, seed=7)
+    out = base.clone()
+    ops.gemm(at, bt, out, trans_a=True, b_kmajor=False, split_k=4, accumulate=True)
+    assert relerr(out, base + pre - bias) < 2e-3
+    out = base.clone()
+    ops.gemm(at, bt, out, trans_a=True, b_kmajor=False, split_k=1, accumulate=True)
+    assert relerr(out, base + pre - bias) < 2e-3
+
+
+def test_gemm_rejects_bad_arguments():
+    ops = _ops()
+    from multimodalsimilar_amd import MmsimError
+    a = torch.zeros(16, 12, dtype=torch.bfloat16, device=DEV)     # lda = 12: not a multiple of 8
+    b = torch.zeros(16, 12, dtype=torch.bfloat16, device=DEV)
+    c = torch.zeros(16, 16, dtype=torch.float32, device=DEV)
+    with pytest.raises(MmsimError):
+        ops.gemm(a, b, c)
+    with pytest.raises(ValueError):
+        ops.gemm(torch.zeros(16, 16, dtype=torch.bfloat16, device=DEV), torch.zeros(8, 24, dtype=torch.bfloat16, device=DEV), c)
+    with pytest.raises(MmsimError):
+        ops.gemm(a.cpu(), b.cpu(), c.cpu())
+
+
+def _attn_ref(qkv, mask, B, S, nh, H):
+    q, k, v = qkv.float().view(B, S, 3, nh, 64).permute(2, 0, 3, 1, 4)
+    sc = q @ k.transpose(-1, -2) / 8.0
+    if mask is not None:
+        sc = sc + torch.zeros(B, 1, 1, S, device=qkv.device).masked_fill(mask.view(B, 1, 1, S) == 0, float("-inf"))
+    p = torch.softmax(sc, -1)
+    return (p @ v).transpose(1, 2).reshape(B * S, H)
+
+
+@pytest.mark.parametrize("S", [32, 64, 128])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attention_fwd_bwd(S, masked):
+    ops = _ops()
+    B, nh = 3, 2
+    H = nh * 64
+    qkv = rnd(B * S, 3 * H, seed=S).bfloat16()
+    mask = None
+    if masked:
+        lens = torch.tensor([S, S // 2 + 3, 5])
+        mask = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).long().to(DEV)
+    ctx = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B * nh * S, dtype=torch.float32, device=DEV)
+    ops.attn_fwd(qkv, mask, ctx, lse, B, S, nh, H)
+    x = qkv.float().requires_grad_(True)
+    ref = _attn_ref(x, mask, B, S, nh, H)
+    assert relerr(ctx, ref) < 1e-2
+    dctx = rnd(B * S, H, seed=S + 1).bfloat16()
+    ref.backward(dctx.float())
+    dqkv = torch.empty_like(qkv)
+    ops.attn_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, nh, H)
+    g = x.grad
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        assert relerr(dqkv[:, sl], g[:, sl]) < 2e-2, name
+
+
+def test_attention_dropout_statistics_and_consistency():
+    ops = _ops()
+    B, nh, S = 2, 2, 128
+    H = nh * 64
+    qkv = rnd(B * S, 3 * H, seed=9).bfloat16()
+    # v = 1 everywhere: ctx = sum_k dropped-P = (#kept mass)/(1-p); its mean over many rows estimates 1
+    qkv[:, 2 * H:] = 1.0
+    ctx = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B * nh * S, dtype=torch.float32, device=DEV)
+    ops.attn_fwd(qkv, None, ctx, lse, B, S, nh, H, dropout_p=0.1, seed=123, stream_id=7)
+    m = ctx.float().mean().item()
+    assert abs(m - 1.0) < 0.02
+    ctx2 = torch.empty_like(ctx)
+    ops.attn_fwd(qkv, None, ctx2, lse, B, S, nh, H, dropout_p=0.1, seed=123, stream_id=7)
+    assert torch.equal(ctx, ctx2)                       # same key -> same mask
+    ops.attn_fwd(qkv, None, ctx2, lse, B, S, nh, H, dropout_p=0.1, seed=124, stream_id=7)
+    assert not torch.equal(ctx, ctx2)
+
+
+@pytest.mark.parametrize("H", [128, 256, 768, 1024])
+def test_add_ln_fwd_bwd(H):
+    ops = _ops()
+    M = 77
+    t = rnd(M, H, seed=1).bfloat16(); r = rnd(M, H, seed=2).bfloat16()
+    gamma = 1 + 0.1 * rnd(H, seed=3); beta = 0.1 * rnd(H, seed=4)
+    y = torch.empty_like(t); h = torch.empty_like(t)
+    mean = torch.empty(M, device=DEV); rstd = torch.empty(M, device=DEV)
+    ops.add_ln_fwd(t, r, gamma, beta, y, h, mean, rstd, 1e-12)
+    yr = (t.float() + r.float()).bfloat16().float().requires_grad_(True)
+    g_ = gamma.clone().requires_grad_(True); b_ = beta.clone().requires_grad_(True)
+    hr = F.layer_norm(yr, (H,), g_, b_, 1e-12)
+    assert relerr(h, hr) < 1e-2 and relerr(y, yr) < 1e-2
+    da = rnd(M, H, seed=5).bfloat16(); db = rnd(M, H, seed=6).bfloat16()
+    hr.backward(da.float() + db.float())
+    dy = torch.empty_like(t)
+    dg = torch.zeros(H, device=DEV); dbt = torch.zeros(H, device=DEV); dbias = torch.zeros(H, device=DEV)
+    ops.ln_bwd(da, db, y, mean, rstd, gamma, dy, None, dg, dbt, dbias)
+    assert relerr(dy, yr.grad) < 1e-2
+    assert relerr(dg, g_.grad) < 1e-2 and relerr(dbt, b_.grad) < 1e-2
+    assert relerr(dbias, dy.float().sum(0)) < 1e-3
+
+
+def test_hidden_dropout_mask_is_replayed_in_backward():
+    ops = _ops()
+    M, H, p = 64, 256, 0.25
+    t = torch.ones(M, H, dtype=torch.bfloat16, device=DEV); r = torch.zeros_like(t)
+    gamma = torch.ones(H, device=DEV); beta = torch.zeros(H, device=DEV)
+    y = torch.empty_like(t); h = torch.empty_like(t)
+    mean = torch.empty(M, device=DEV); rstd = torch.empty(M, device=DEV)
+    ops.add_ln_fwd(t, r, gamma, beta, y, h, mean, rstd, 1e-12, p, 42, 3)
+    keep = (y.float() != 0)
+    assert abs(keep.float().mean().item() - (1 - p)) < 0.02
+    assert torch.allclose(y.float()[keep], torch.full_like(y.float()[keep], 1 / (1 - p)), rtol=1e-2)
+    dy = torch.empty_like(t); dt = torch.empty_like(t)
+    dh = rnd(M, H, seed=8).bfloat16()
+    z = torch.zeros(H, device=DEV)
+    ops.ln_bwd(dh, None, y, mean, rstd, gamma, dy, dt, z.clone(), z.clone(), z.clone(), p, 42, 3)
+    assert torch.equal(dt.float() != 0, keep & (dy.float() != 0))
+    assert relerr(dt.float()[keep], dy.float()[keep] / (1 - p)) < 1e-2
+
+
+def test_embed_ln_fwd_bwd():
+    ops = _ops()
+    B, S, H, V = 5, 32, 256, 50
+    word = rnd(V, H, seed=1, scale=0.5); pos = rnd(64, H, seed=2, scale=0.5); typ = rnd(2, H, seed=3, scale=0.5)
+    gamma = 1 + 0.1 * rnd(H, seed=4); beta = 0.1 * rnd(H, seed=5)
+    ids = torch.randint(0, V, (B, S), device=DEV); tts = torch.randint(0, 2, (B, S), device=DEV)
+    out = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV)
+    ops.embed_ln_fwd(ids, tts, word, pos, typ, gamma, beta, out, B, S, H, 1e-12)
+    ws = [t.clone().requires_grad_(True) for t in (word, pos, typ, gamma, beta)]
+    e = ws[0][ids] + ws[2][tts] + ws[1][torch.arange(S, device=DEV)].unsqueeze(0)
+    ref = F.layer_norm(e, (H,), ws[3], ws[4], 1e-12).view(B * S, H)
+    assert relerr(out, ref) < 1e-2
+    dout = rnd(B * S, H, seed=6).bfloat16()
+    ref.backward(dout.float())
+    gs = [torch.zeros_like(t) for t in (word, pos, typ, gamma, beta)]
+    ops.embed_ln_bwd(dout, ids, tts, word, pos, typ, gamma, gs[0], gs[1], gs[2], gs[3], gs[4], B, S, H, 1e-12)
+    for g, w, n in zip(gs, ws, ("word", "pos", "type", "gamma", "beta")):
+        assert relerr(g, w.grad) < 2e-3, n
+
+
+def test_colsum_and_l2norm():
+    ops = _ops()
+    x = rnd(1000, 264, seed=1).bfloat16()
+    out = torch.zeros(264, device=DEV)
+    ops.colsum(x, out)
+    assert relerr(out, x.float().sum(0)) < 1e-4
+    v = rnd(33, 512, seed=2, scale=3.0).requires_grad_(True)
+    of = torch.zeros(33, 640, device=DEV); inv = torch.empty(33, device=DEV)
+    ops.l2norm_fwd(v.detach(), of, None, 128, inv)
+    ref = F.normalize(v, dim=1)
+    assert torch.allclose(of[:, 128:], ref, atol=1e-6) and of[:, :128].abs().max() == 0
+    g = rnd(33, 640, seed=3)
+    ref.backward(g[:, 128:])
+    dx = torch.empty(33, 512, device=DEV)
+    ops.l2norm_bwd(v.detach(), inv, g, 128, dx)
+    assert torch.allclose(dx, v.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_adamw_matches_golden(golden_dir):
+    import numpy as np, os
+    ops = _ops()
+    from oracle import optim_ref
+    d = np.load(os.path.join(golden_dir, "adamw_fc.npz"))
+    lr0, warm, total = float(d["lr0"]), float(d["warmup"]), int(d["total"])
+    shapes = [d[f"p0_{j}"].shape for j in range(3)]
+    sizes = [int(np.prod(s)) for s in shapes]
+    offs = [0, 40, 56]
+    n = 72
+    p = torch.zeros(n, device=DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    sh = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    for j in range(3):
+        p[offs[j]:offs[j] + sizes[j]] = torch.from_numpy(d[f"p0_{j}"]).flatten().to(DEV)
+    for t in range(total):
+        g = torch.zeros(n, device=DEV)
+        for j in range(3):
+            g[offs[j]:offs[j] + sizes[j]] = torch.from_numpy(d[f"g{t}_{j}"]).flatten().to(DEV)
+        ops.adamw_step(p, g, m, v, sh, optim_ref.linear_lr(lr0, t, warm, total), 0.9, 0.999, 1e-8, 0.01, t + 1)
+        for j in range(3):
+            ref = torch.from_numpy(d[f"p{t + 1}_{j}"]).flatten().to(DEV)
+            assert torch.allclose(p[offs[j]:offs[j] + sizes[j]], ref, rtol=2e-5, atol=1e-6)
+    assert torch.equal(sh, p.bfloat16())

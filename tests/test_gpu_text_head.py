@@ -1,0 +1,159 @@
+"""Module-level parity on the MI355X against the fixtures produced by RUNNING THE REFERENCE
+(tests/golden/gen_golden.py) and against the CPU oracle on fresh seeded inputs.
+bf16 compute path: tolerance 1e-2 relative to the tensor's scale (BASELINE.json north_star)."""
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+T = torch.from_numpy
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def _load(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+@pytest.mark.parametrize("i", range(5))
+def test_arcface_head_matches_reference_golden(golden_dir, i):
+    from arcface import ArcMarginProduct
+    d = _load(golden_dir, f"arcface_{i}.npz")
+    B, D = d["x"].shape
+    C = d["weight"].shape[0]
+    head = ArcMarginProduct(D, C, s=float(d["s"]), m=float(d["m"]), easy_margin=bool(int(d["easy"])))
+    with torch.no_grad():
+        head.weight.copy_(T(d["weight"]))
+    head.to(DEV)
+    x = T(d["x"]).to(DEV).requires_grad_(True)
+    y = T(d["label"]).to(DEV)
+    # API path: materialised logits + torch CE (the reference's loop, multimodal_classifier_train.py:182-189)
+    logits = head(x, y)
+    assert logits.shape == (B, C)
+    assert (logits.cpu() - T(d["logits"])).abs().max() < 0.35          # |logit| <= 64, bf16 cosines
+    loss = torch.nn.CrossEntropyLoss()(logits, y)
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) < 2e-2 * max(1.0, abs(float(d["loss"])))
+    assert relerr(x.grad, T(d["dx"])) < 3e-2
+    assert relerr(head.weight.grad, T(d["dw"])) < 3e-2
+    assert (head.forward_test(x.detach()).cpu() - T(d["logits_test"])).abs().max() < 6e-3
+    # fused path: same numbers without the logits
+    gx1, gw1 = x.grad.clone(), head.weight.grad.clone()
+    x.grad = None
+    head.weight.grad.zero_()
+    loss2, am = head.forward_loss(x, y)
+    loss2.backward()
+    assert abs(loss2.item() - loss.item()) < 1e-3 * max(1.0, abs(loss.item()))
+    assert relerr(x.grad, gx1) < 1e-3 and relerr(head.weight.grad, gw1) < 1e-3
+    assert torch.equal(am.cpu(), logits.argmax(1).cpu())
+
+
+def test_arcface_label_out_of_range_raises():
+    from arcface import ArcMarginProduct
+    head = ArcMarginProduct(32, 10).to(DEV)
+    x = torch.randn(4, 32, device=DEV)
+    with pytest.raises(IndexError):
+        head(x, torch.tensor([0, 1, 10, 2], device=DEV))
+
+
+def test_glue_matches_reference_golden(golden_dir):
+    from arcface import ArcMarginProduct
+    from multimodalsimilar_amd.head import glue_concat
+    d = _load(golden_dir, "glue_0.npz")
+    img = T(d["img"]).to(DEV).requires_grad_(True)
+    txt = T(d["txt"]).to(DEV).requires_grad_(True)
+    head = ArcMarginProduct(img.shape[1] + txt.shape[1], d["weight"].shape[0], m=0.5)
+    with torch.no_grad():
+        head.weight.copy_(T(d["weight"]))
+    head.to(DEV)
+    final = glue_concat(img, txt)
+    assert torch.allclose(final.cpu(), T(d["final"]), atol=1e-6)
+    loss, _ = head.forward_loss(final, T(d["label"]).to(DEV))
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) < 2e-2 * max(1.0, float(d["loss"]))
+    assert relerr(img.grad, T(d["dimg"])) < 3e-2 and relerr(txt.grad, T(d["dtxt"])) < 3e-2
+    assert relerr(head.weight.grad, T(d["dw"])) < 3e-2
+
+
+def _build_nlp(d, name):
+    from tests.test_oracle import nlp_state_from_golden
+    from multimodalsimilar_amd.bert import BertModel, BertConfig
+    from nlp_classifier import NlpClassifier
+    shape, sd = nlp_state_from_golden(d, name)
+    cfg = BertConfig(vocab_size=shape.vocab_size, hidden_size=shape.hidden_size,
+                     num_hidden_layers=shape.num_hidden_layers, num_attention_heads=shape.num_attention_heads,
+                     intermediate_size=shape.intermediate_size, max_position_embeddings=shape.max_position_embeddings,
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    ptm = BertModel(cfg)
+    ptm.load_state_dict(sd)
+    model = NlpClassifier(ptm, num_labels=d["head_weight"].shape[0])
+    with torch.no_grad():
+        model.classifier.weight.copy_(T(d["head_weight"]))
+    return model.to(DEV), shape, sd
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_nlp_classifier_matches_reference_golden(golden_dir, name):
+    d = _load(golden_dir, f"nlp_{name}.npz")
+    model, shape, sd = _build_nlp(d, name)
+    model.train()
+    ids, tt, mask, y = (T(d[k]).to(DEV) for k in ("input_ids", "token_type_ids", "attention_mask", "label"))
+    emb = model.predict_emb(ids, tt, None, mask)
+    assert relerr(emb, T(d["pooled"])) < 1e-2
+    logits = model(ids, tt, None, mask, y)
+    assert (logits.cpu() - T(d["logits"])).abs().max() < 0.64          # 1e-2 of the 64-scale
+    loss = torch.nn.CrossEntropyLoss()(logits, y)
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) < 2e-2 * float(d["loss"])
+    assert relerr(model.classifier.weight.grad, T(d["head_grad"])) < 5e-2
+    named = dict(model.ptm.named_parameters())
+    worst = 0.0
+    for k, v in d.items():
+        if k.startswith("g::"):
+            e = relerr(named[k[3:]].grad, T(v))
+            worst = max(worst, e)
+            assert e < 6e-2, (k, e)
+        if k.startswith("gnorm::"):
+            g = named[k[7:]].grad.float().norm().item()
+            assert abs(g - float(v)) < 6e-2 * float(v) + 1e-6, (k, g, float(v))
+    logits_test = model(ids, tt, None, mask, y, is_test=True)
+    assert (logits_test.cpu() - T(d["logits_test"])).abs().max() < 1e-2
+
+
+def test_text_tower_against_oracle_fresh_inputs():
+    """cfg-1 shaped (roberta-base width, 2 layers, S=64) forward/backward vs the CPU oracle, fused loss path."""
+    from oracle import bert_ref, arcface_ref
+    from multimodalsimilar_amd.bert import BertModel, BertConfig
+    from nlp_classifier import NlpClassifier
+    shape = bert_ref.BertShape(vocab_size=500, hidden_size=768, num_hidden_layers=2, num_attention_heads=12,
+                               intermediate_size=3072, max_position_embeddings=64)
+    sd = bert_ref.init_state(shape, seed=3)
+    cfg = BertConfig(vocab_size=500, hidden_size=768, num_hidden_layers=2, num_attention_heads=12,
+                     intermediate_size=3072, max_position_embeddings=64, hidden_dropout_prob=0.0,
+                     attention_probs_dropout_prob=0.0)
+    ptm = BertModel(cfg)
+    ptm.load_state_dict(sd)
+    model = NlpClassifier(ptm, num_labels=1000).to(DEV).train()
+    g = torch.Generator().manual_seed(4)
+    B, S = 8, 64
+    ids = torch.randint(0, 500, (B, S), generator=g)
+    mask = (torch.arange(S).unsqueeze(0) < torch.randint(8, S + 1, (B, 1), generator=g)).long()
+    y = torch.randint(0, 1000, (B,), generator=g)
+    hw = model.classifier.weight.detach().cpu().clone().requires_grad_(True)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pooled = bert_ref.bert_forward(sdr, shape, ids, None, mask)
+    ref_loss = arcface_ref.ce_loss(arcface_ref.arcface_forward(pooled, hw, y, 64.0, 0.40), y)
+    ref_loss.backward()
+    loss, am = model.forward_loss(ids.to(DEV), None, None, mask.to(DEV), y.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 2e-2 * ref_loss.item()
+    named = dict(model.ptm.named_parameters())
+    for k in ("pooler.dense.weight", "encoder.layer.1.output.dense.weight", "encoder.layer.0.attention.self.key.weight",
+              "encoder.layer.0.intermediate.dense.bias", "embeddings.LayerNorm.weight",
+              "embeddings.position_embeddings.weight"):
+        assert relerr(named[k].grad, sdr[k].grad) < 6e-2, k
