@@ -44,10 +44,10 @@ def test_gemm_layouts(M, N, K, layout):
         A, Bm, kw = a, b.t().contiguous(), dict(b_kmajor=False)
     else:
         A, Bm, kw = a.t().contiguous(), b.t().contiguous(), dict(trans_a=True, b_kmajor=False)
-    c = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    c = ops.alloc_2d(M, N, torch.float32, DEV)
     ops.gemm(A, Bm, c, **kw)
     assert relerr(c, ref) < 2e-3
-    cb = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    cb = ops.alloc_2d(M, N, torch.bfloat16, DEV)
     ops.gemm(A, Bm, cb, **kw)
     assert relerr(cb, ref) < 1e-2
 

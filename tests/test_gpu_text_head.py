@@ -114,6 +114,12 @@ def test_nlp_classifier_matches_reference_golden(golden_dir, name):
     named = dict(model.ptm.named_parameters())
     worst = 0.0
     for k, v in d.items():
+        if k.endswith("attention.self.key.bias"):
+            # softmax is invariant to a per-query constant, so d(loss)/d(key.bias) == 0 analytically; the reference
+            # holds ~1e-9 of fp32 noise there.  Ours must be noise as well, measured against the query-bias gradient.
+            qb = named[k.split("::")[1].replace("key.bias", "query.bias")].grad.float().norm().item()
+            assert named[k.split("::")[1]].grad.float().norm().item() < 2e-2 * qb, k
+            continue
         if k.startswith("g::"):
             e = relerr(named[k[3:]].grad, T(v))
             worst = max(worst, e)
