@@ -40,6 +40,14 @@ int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, const void* 
                     void* C, int ldc, int c_is_f32, const float* bias, int epilogue, const void* aux_in,
                     void* aux_out, int ld_aux, float alpha, int split_k, int accumulate, void* stream);
 
+/* 1x1 conv whose input is the previous BatchNorm + SiLU (+ squeeze-excite gate) applied while the operand is
+ * staged: x -> silu(xf_scale[c] x + xf_shift[c]) * xf_gate[pixel / xf_hw, c]  (gate may be NULL).
+ *   xf_operand 1 (forward): C[P,Cout] = xf(A)[P,Cin] B[Cout,Cin]^T;  2 (wgrad): C[Cout,Cin] (+)= A[P,Cout]^T xf(B)[P,Cin].
+ * Replaces timm's conv_pwl / conv_pw after bn+act+se inside the MBConv blocks under cv_classifier.py:49. */
+int mmsim_gemm_bf16_xf(int xf_operand, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                       int ldc, int c_is_f32, const float* xf_scale, const float* xf_shift, const float* xf_gate,
+                       int xf_hw, int split_k, int accumulate, void* stream);
+
 /* ---- self-attention (modeling_bert.py:111-136, 164-203), head_dim 64, S in {32, 64, 128} ----------
  * qkv: bf16 [B*S, ld_qkv] with q | k | v column blocks of width H; mask: int64 [B,S] (1 keep / 0 pad)
  * or NULL; ctx: bf16 [B*S, ld_ctx]; lse: fp32 [B*heads*S] log-sum-exp saved for backward. */
@@ -102,6 +110,58 @@ int mmsim_cast_bf16_to_f32(const void* x, float* y, unsigned long long n, void* 
 int mmsim_gather_cls(const void* h, void* out, int B, int S, int H, void* stream);     /* h[:,0] (modeling_bert.py:460) */
 int mmsim_scatter_cls(const void* src, void* dh, int B, int S, int H, void* stream);   /* its backward */
 int mmsim_tanh_bwd(const float* dpooled, const float* pooled, void* dpre, unsigned long long n, void* stream);
+
+/* ---- EfficientNet image tower (timm efficientnet_b0/b4 under cv_classifier.py:23-27,49), NHWC bf16 activations.
+ * Train-mode BatchNorm2d (eps 1e-5, momentum 0.1): bn_stats accumulates per-channel sum / sum of squares into
+ * sums [2][C] (fp32, pre-zeroed); bn_finalize turns them into mean, rstd, scale = gamma*rstd,
+ * shift = beta - mean*scale and updates the running statistics; bn_apply writes act(scale*z+shift) (+resid). */
+int mmsim_bn_stats(const void* z, float* sums, int P, int C, void* stream);
+int mmsim_bn_finalize(const float* sums, const float* gamma, const float* beta, float* mean, float* rstd, float* scale,
+                      float* shift, float* run_mean, float* run_var, int C, float count, float eps, float momentum,
+                      void* stream);
+int mmsim_bn_apply(const void* z, const float* scale, const float* shift, const void* resid, void* out, int P, int C,
+                   int act_silu, void* stream);
+/* out[b,c] = mul * sum_hw act(scale*z+shift) * (other ? other : 1): SE squeeze / global pool (mul = 1/HW), SE dgate. */
+int mmsim_pool_bn_act(const void* z, const float* scale, const float* shift, const void* other, float* out, int B,
+                      int HW, int C, int act_silu, float mul, void* stream);
+/* Squeeze-excite: gate = sigmoid(W_expand silu(W_reduce s + b_reduce) + b_expand); hr = pre-activation (saved). */
+int mmsim_se_mlp_fwd(const float* s, const float* w_reduce, const float* b_reduce, const float* w_expand,
+                     const float* b_expand, float* hr, float* gate, int B, int C, int RD, void* stream);
+int mmsim_se_mlp_bwd(const float* dgate, const float* gate, const float* hr, const float* s, const float* w_reduce,
+                     const float* w_expand, float* dpe, float* dr, float* ds, float* dw_reduce, float* db_reduce,
+                     float* dw_expand, float* db_expand, int B, int C, int RD, void* stream);
+/* BatchNorm (+SiLU, +SE gate) backward: da = (gate ? dy*gate + dsq/hw : dy) * (act ? silu'(scale*z+shift) : 1);
+ * dz = scale*(da - mean(da) - zhat*mean(da*zhat)); dgamma += sum da*zhat; dbeta += sum da.
+ * sums [2][C] must be zero on entry unless sums_ready (already produced by mmsim_dwconv_bwd_data). */
+int mmsim_bn_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* scale,
+                 const float* shift, const float* gate, const float* dsq, int hw, int act_silu, float* sums,
+                 int sums_ready, void* dz, float* dgamma, float* dbeta, int P, int C, void* stream);
+/* Depthwise k3/k5 stride 1/2 conv, pad k/2.  Weights in tap-major fp32 [K*K][C] (see the two converters).
+ * fwd also accumulates the output's BN sums; bwd_data also applies silu'(bn(z1)) of the producer and
+ * accumulates that BatchNorm's backward sums (z1 == NULL: plain transposed conv, + resid if given);
+ * bwd_weight accumulates into a tap-major gradient. */
+int mmsim_dw_weight_to_tap_major(const float* w, float* wT, int C, int K, void* stream);
+int mmsim_dw_grad_from_tap_major(const float* gT, float* g, int C, int K, void* stream);
+int mmsim_dwconv_fwd(const void* a, const float* w_tap_major, void* z, float* sums, int B, int Hi, int Wi, int C, int K,
+                     int S, void* stream);
+int mmsim_dwconv_bwd_data(const void* dz, const float* w_tap_major, const void* z1, const float* mean, const float* rstd,
+                          const float* scale, const float* shift, const void* resid, void* dpre, float* sums, int B,
+                          int Hi, int Wi, int C, int K, int S, void* stream);
+int mmsim_dwconv_bwd_weight(const void* dz, const void* a, float* g_tap_major, int B, int Hi, int Wi, int C, int K, int S,
+                            void* stream);
+/* Stem: 3x3 stride-2 pad-1 conv on the NCHW fp32 image -> NHWC bf16, with the output's BN sums; and its wgrad. */
+int mmsim_stem_fwd(const float* x, const float* w, void* z, float* sums, int B, int Hi, int Wi, int Co, void* stream);
+int mmsim_stem_wgrad(const void* dz, const float* x, float* dw, int B, int Hi, int Wi, int Co, void* stream);
+/* Tower top (cv_classifier.py:50-54): dropout -> bf16, BatchNorm1d on fp32 [B,C], pool backward broadcast. */
+int mmsim_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                   float* run_mean, float* run_var, int B, int C, float eps, float momentum, int training, void* stream);
+int mmsim_bn1d_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx,
+                   float* dgamma, float* dbeta, int B, int C, void* stream);
+int mmsim_dropout_cast(const float* x, void* y_bf16, unsigned long long n, float p, unsigned long long seed,
+                       unsigned int stream_id, void* stream);
+int mmsim_dropout_bwd(const float* dy, float* dx, unsigned long long n, float p, unsigned long long seed,
+                      unsigned int stream_id, void* stream);
+int mmsim_broadcast_pool_grad(const float* dpool, void* dy, int B, int HW, int C, void* stream);
 
 /* ---- torch.optim.AdamW.step() (multimodal_classifier_train.py:152-156,161,195,199) over a flat fp32 buffer.
  * g is multiplied by grad_scale first (1/world_size after an all-reduce sum); bf16_shadow (may be NULL)

@@ -1,0 +1,55 @@
+"""Drop-in for the reference's ``multimodal_classifier`` module (multimodal_classifier.py:13-57): the two-tower
+model -- image tower + text tower, each embedding L2-normalised, concatenated, ArcFace(m=0.5) head.
+
+Same constructor / attributes (cv, nlp, classifier, dropout, num_labels, emb_size) / ``forward`` / ``predict_emb``.
+``cv_classifier_path`` / ``nlp_classifier_path`` may be whole-module pickle paths as in the reference
+(``torch.load(..., weights_only=False)``, E10) or already-constructed CvClassifier / NlpClassifier modules
+(offline there is nothing to download or unpickle).  ``forward_loss`` is the fused training path.
+"""
+import torch
+import torch.nn as nn
+
+from arcface import ArcMarginProduct
+from multimodalsimilar_amd.head import glue_concat
+
+
+def _load_tower(obj):
+    if isinstance(obj, nn.Module):
+        return obj
+    return torch.load(obj, weights_only=False)          # multimodal_classifier.py:16-17
+
+
+class MultimodalClassifier(nn.Module):
+    def __init__(self, device, cv_classifier_path, nlp_classifier_path, emb_size, num_labels, dropout=None):
+        super().__init__()
+        self.cv = _load_tower(cv_classifier_path)
+        self.nlp = _load_tower(nlp_classifier_path)
+        self.dropout = nn.Dropout(p=dropout if dropout is not None else 0.1)     # never applied (reference :18, E6)
+        self.num_labels = num_labels
+        self.emb_size = emb_size
+        self.classifier = ArcMarginProduct(in_feature=self.emb_size, out_feature=self.num_labels, m=0.5)   # :22
+        self.cv.to(device)
+        self.nlp.to(device)
+        self.classifier.to(device)
+
+    def forward(self, img_input: torch.Tensor, query_input_ids, query_token_type_ids=None, query_position_ids=None,
+                query_attention_mask=None, label=None, is_test=False):
+        final_embdding = self.predict_emb(img_input=img_input, query_input_ids=query_input_ids,
+                                          query_token_type_ids=query_token_type_ids,
+                                          query_attention_mask=query_attention_mask)
+        if not is_test:
+            return self.classifier(final_embdding, label)
+        return self.classifier.forward_test(final_embdding)
+
+    def forward_loss(self, img_input, query_input_ids, query_token_type_ids=None, query_position_ids=None,
+                     query_attention_mask=None, label=None):
+        """(mean cross-entropy of the margin logits, argmax) without materialising the [B, C] logits."""
+        emb = self.predict_emb(img_input, query_input_ids, query_token_type_ids, None, query_attention_mask)
+        return self.classifier.forward_loss(emb, label)
+
+    def predict_emb(self, img_input: torch.Tensor, query_input_ids, query_token_type_ids=None, query_position_ids=None,
+                    query_attention_mask=None):
+        img_embedding = self.cv.predict_emb(img_input)
+        title_embedding = self.nlp.predict_emb(query_input_ids=query_input_ids, query_token_type_ids=query_token_type_ids,
+                                               query_attention_mask=query_attention_mask)   # position ids dropped (E13)
+        return glue_concat(img_embedding, title_embedding)                                   # :54-56

@@ -1,0 +1,845 @@
+// EfficientNet (MBConv) kernels for gfx950, NHWC bf16 activations, fp32 statistics.
+// The image tower is HBM-bound: every kernel here maps a thread to one 8-channel octet
+// (one 16-byte access) so a wave reads whole contiguous pixel rows, keeps its channel octet fixed so
+// per-channel reductions (BatchNorm batch statistics, BN/SE backward sums, depthwise weight gradients)
+// accumulate in registers, and leaves a block as ONE atomic per channel.
+//   bn_stats / bn_finalize / bn_apply          train-mode BatchNorm2d (eps 1e-5, momentum 0.1) + SiLU
+//   pool_bn_act                                mean_HW act(bn(z)) [* other]  (SE squeeze, global pool, dgate)
+//   se_mlp_fwd / se_mlp_bwd / se_wgrad         squeeze-excite 1x1 convs (bias) + SiLU + sigmoid
+//   bn_bwd_reduce / bn_bwd_apply               BN (+SiLU, +SE gate) backward
+//   dwconv_fwd / dwconv_bwd_data / dwconv_bwd_weight   depthwise k3/k5, stride 1/2
+//   stem_fwd / stem_wgrad                      3x3 s2 conv on the NCHW fp32 input image
+//   bn1d_fwd / bn1d_bwd                        BatchNorm1d after the fc layer (cv_classifier.py:54)
+// Pointwise (1x1) convs are GEMMs over [pixels, channels] (gemm.hip), optionally with the BN+SiLU+gate
+// transform fused into the operand load.
+#include "common.h"
+
+struct CgMap { int G, nr, cg, rl; bool active; };
+__device__ __forceinline__ CgMap cg_map(int C) {
+  CgMap m;
+  m.G = C >> 3;
+  if (m.G >= 256) { m.nr = 1; m.rl = 0; m.cg = blockIdx.y * 256 + threadIdx.x; m.active = m.cg < m.G; }
+  else { m.nr = 256 / m.G; m.cg = threadIdx.x % m.G; m.rl = threadIdx.x / m.G; m.active = m.rl < m.nr; }
+  return m;
+}
+static inline int cg_grid_y(int C) { const int G = C >> 3; return G >= 256 ? (G + 255) / 256 : 1; }
+
+// reduce acc[NV] over the row-lanes of a block (same channel octet) and atomically add into dst
+// (dst[i] base for value i: dst_i = base + (i/8)*stat_stride + c0 + i%8)
+template <int NV>
+__device__ __forceinline__ void block_reduce_atomic(float (&acc)[NV], const CgMap& m, float* lds, float* base,
+                                                    size_t stat_stride) {
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) lds[threadIdx.x * NV + i] = acc[i];
+  __syncthreads();
+  if (m.active && m.rl == 0) {
+    for (int r = 1; r < m.nr; ++r)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) acc[i] += lds[(m.cg + r * m.G) * NV + i];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) atomicAdd(base + (size_t)(i >> 3) * stat_stride + m.cg * 8 + (i & 7), acc[i]);
+  }
+}
+
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+  const bf8 b = __builtin_bit_cast(bf8, v);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = bf2f(b[e]);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  bf8 b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) b[e] = f2bf(f[e]);
+  return __builtin_bit_cast(uint4, b);
+}
+__device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+// ------------------------------------------------------------------ BN statistics
+__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* z, float* sums, int P, int C, int rows_per_block) {
+  __shared__ float lds[256 * 16];
+  const CgMap m = cg_map(C);
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (m.active) {
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(P, r0 + rows_per_block);
+    for (int r = r0 + m.rl; r < r1; r += m.nr) {
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(z + (size_t)r * C + m.cg * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { acc[e] += f[e]; acc[8 + e] += f[e] * f[e]; }
+    }
+  }
+  block_reduce_atomic<16>(acc, m, lds, sums, (size_t)C);
+}
+
+// sums [2][C] -> mean, rstd, scale = gamma*rstd, shift = beta - mean*scale; running stats (momentum, unbiased var)
+__global__ void bn_finalize_kernel(const float* sums, const float* gamma, const float* beta, float* mean, float* rstd,
+                                   float* scale, float* shift, float* run_mean, float* run_var, int C, float count,
+                                   float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mu = sums[c] / count;
+  const float var = fmaxf(sums[C + c] / count - mu * mu, 0.f);
+  const float rs = rsqrtf(var + eps);
+  mean[c] = mu; rstd[c] = rs;
+  const float sc = gamma[c] * rs;
+  scale[c] = sc; shift[c] = beta[c] - mu * sc;
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
+  }
+}
+
+// out = act(scale*z + shift) (+ resid)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* z, const float* scale, const float* shift,
+                                                       const bf16* resid, bf16* out, size_t nchunks, int C, int act) {
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nchunks; q += (size_t)gridDim.x * 256) {
+    const int c0 = (int)((q * 8) % (size_t)C);
+    float f[8], sc[8], sh[8];
+    unpack8(*reinterpret_cast<const uint4*>(z + q * 8), f);
+    ld8f(scale + c0, sc); ld8f(shift + c0, sh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { f[e] = f[e] * sc[e] + sh[e]; if (act) f[e] = silu_f(f[e]); }
+    if (resid) {
+      float r[8];
+      unpack8(*reinterpret_cast<const uint4*>(resid + q * 8), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += r[e];
+    }
+    *reinterpret_cast<uint4*>(out + q * 8) = pack8(f);
+  }
+}
+
+// out[b,c] = mul * sum_hw act(scale*z+shift)[b,hw,c] * (other ? other[b,hw,c] : 1)      (fp32 [B,C])
+__global__ __launch_bounds__(256) void pool_bn_act_kernel(const bf16* z, const float* scale, const float* shift,
+                                                          const bf16* other, float* out, int HW, int C, int act, float mul) {
+  __shared__ float lds[256 * 8];
+  const CgMap m = cg_map(C);
+  const int b = blockIdx.x;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (m.active) {
+    float sc[8], sh[8];
+    ld8f(scale + m.cg * 8, sc); ld8f(shift + m.cg * 8, sh);
+    for (int r = m.rl; r < HW; r += m.nr) {
+      const size_t off = ((size_t)b * HW + r) * C + m.cg * 8;
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(z + off), f);
+      if (other) {
+        float o[8];
+        unpack8(*reinterpret_cast<const uint4*>(other + off), o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float y = f[e] * sc[e] + sh[e]; if (act) y = silu_f(y); acc[e] += y * o[e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float y = f[e] * sc[e] + sh[e]; if (act) y = silu_f(y); acc[e] += y; }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) lds[threadIdx.x * 8 + e] = acc[e];
+  __syncthreads();
+  if (m.active && m.rl == 0) {
+    for (int r = 1; r < m.nr; ++r)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += lds[(m.cg + r * m.G) * 8 + e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[(size_t)b * C + m.cg * 8 + e] = acc[e] * mul;
+  }
+}
+
+// ------------------------------------------------------------------ squeeze-excite MLP
+// s [B,C] -> hr = Wr s + br (pre-activation, saved) -> gate = sigmoid(We silu(hr) + be)
+__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* s, const float* Wr, const float* br, const float* We,
+                                                         const float* be, float* hr_out, float* gate, int C, int RD) {
+  extern __shared__ float sm[];
+  float* sv = sm;            // [C]
+  float* hv = sm + C;        // [RD]
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < C; c += 256) sv[c] = s[(size_t)b * C + c];
+  __syncthreads();
+  for (int j = wv; j < RD; j += 4) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a += Wr[(size_t)j * C + c] * sv[c];
+    a = wave_sum(a) + br[j];
+    if (lane == 0) { hr_out[(size_t)b * RD + j] = a; hv[j] = silu_f(a); }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = be[c];
+    for (int j = 0; j < RD; ++j) a += We[(size_t)c * RD + j] * hv[j];
+    gate[(size_t)b * C + c] = sigmoid_f(a);
+  }
+}
+
+// dgate [B,C] -> dpe = dgate*g*(1-g) (saved) ; dr = (We^T dpe) * silu'(hr) (saved) ; ds = Wr^T dr
+__global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* dgate, const float* gate, const float* hr,
+                                                         const float* Wr, const float* We, float* dpe_out, float* dr_out,
+                                                         float* ds, int C, int RD) {
+  extern __shared__ float sm[];
+  float* dv = sm;            // dpe [C]
+  float* rv = sm + C;        // dr [RD]
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float g = gate[(size_t)b * C + c];
+    const float d = dgate[(size_t)b * C + c] * g * (1.f - g);
+    dv[c] = d; dpe_out[(size_t)b * C + c] = d;
+  }
+  __syncthreads();
+  for (int j = wv; j < RD; j += 4) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a += We[(size_t)c * RD + j] * dv[c];
+    a = wave_sum(a) * silu_grad_f(hr[(size_t)b * RD + j]);
+    if (lane == 0) { rv[j] = a; dr_out[(size_t)b * RD + j] = a; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f;
+    for (int j = 0; j < RD; ++j) a += Wr[(size_t)j * C + c] * rv[j];
+    ds[(size_t)b * C + c] = a;
+  }
+}
+
+// weight gradients of the two SE convs (reductions over the batch); thread per (c, j)
+__global__ __launch_bounds__(256) void se_wgrad_kernel(const float* dpe, const float* dr, const float* hr, const float* s,
+                                                       float* dWr, float* dbr, float* dWe, float* dbe, int B, int C, int RD) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= C * RD) return;
+  const int c = idx / RD, j = idx % RD;
+  float ae = 0.f, ar = 0.f, ab = 0.f, abr = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float d = dpe[(size_t)b * C + c], r = dr[(size_t)b * RD + j];
+    ae += d * silu_f(hr[(size_t)b * RD + j]);
+    ar += r * s[(size_t)b * C + c];
+    ab += d; abr += r;
+  }
+  dWe[(size_t)c * RD + j] += ae;
+  dWr[(size_t)j * C + c] += ar;
+  if (j == 0) dbe[c] += ab;
+  if (c == 0) dbr[j] += abr;
+}
+
+// ------------------------------------------------------------------ BN (+SiLU, +SE gate) backward
+struct BnBwd {
+  const bf16* dy; const bf16* z; const float* mean; const float* rstd; const float* scale; const float* shift;
+  const float* gate; const float* dsq; int hw; int act; int P; int C; float inv_hw;
+};
+// da = (gate ? dy*g + dsq/HW : dy) * (act ? silu'(scale*z+shift) : 1)
+__device__ __forceinline__ void bn_bwd_elem(const BnBwd& p, int r, int c0, float (&da)[8], float (&zh)[8]) {
+  const size_t off = (size_t)r * p.C + c0;
+  float d[8], z[8], mu[8], rs[8];
+  unpack8(*reinterpret_cast<const uint4*>(p.dy + off), d);
+  unpack8(*reinterpret_cast<const uint4*>(p.z + off), z);
+  ld8f(p.mean + c0, mu); ld8f(p.rstd + c0, rs);
+  if (p.gate) {
+    const int b = r / p.hw;
+    float g[8], q[8];
+    ld8f(p.gate + (size_t)b * p.C + c0, g); ld8f(p.dsq + (size_t)b * p.C + c0, q);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] = d[e] * g[e] + q[e] * p.inv_hw;
+  }
+  if (p.act) {
+    float sc[8], sh[8];
+    ld8f(p.scale + c0, sc); ld8f(p.shift + c0, sh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] *= silu_grad_f(z[e] * sc[e] + sh[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { da[e] = d[e]; zh[e] = (z[e] - mu[e]) * rs[e]; }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwd p, float* sums, int rows_per_block) {
+  __shared__ float lds[256 * 16];
+  const CgMap m = cg_map(p.C);
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (m.active) {
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(p.P, r0 + rows_per_block);
+    for (int r = r0 + m.rl; r < r1; r += m.nr) {
+      float da[8], zh[8];
+      bn_bwd_elem(p, r, m.cg * 8, da, zh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { acc[e] += da[e]; acc[8 + e] += da[e] * zh[e]; }
+    }
+  }
+  block_reduce_atomic<16>(acc, m, lds, sums, (size_t)p.C);
+}
+
+// dz = scale * (da - S1/P - zh*S2/P); block 0 also does dgamma += S2, dbeta += S1
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwd p, const float* sums, bf16* dz, float* dgamma, float* dbeta,
+                                                           int rows_per_block) {
+  const CgMap m = cg_map(p.C);
+  if (blockIdx.x == 0 && dgamma) {
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < p.C; c += 256 * gridDim.y) { dgamma[c] += sums[p.C + c]; dbeta[c] += sums[c]; }
+  }
+  if (!m.active) return;
+  const int c0 = m.cg * 8;
+  float s1[8], s2[8], sc[8];
+  ld8f(sums + c0, s1); ld8f(sums + p.C + c0, s2); ld8f(p.scale + c0, sc);
+  const float invP = 1.0f / (float)p.P;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(p.P, r0 + rows_per_block);
+  for (int r = r0 + m.rl; r < r1; r += m.nr) {
+    float da[8], zh[8], o[8];
+    bn_bwd_elem(p, r, c0, da, zh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = sc[e] * (da[e] - s1[e] * invP - zh[e] * s2[e] * invP);
+    *reinterpret_cast<uint4*>(dz + (size_t)r * p.C + c0) = pack8(o);
+  }
+}
+
+// ------------------------------------------------------------------ depthwise conv
+// weights are used in tap-major layout wT [K*K][C] (fp32) so a thread reads its 8 channels contiguously
+__global__ void dw_weight_to_tap_major_kernel(const float* w, float* wT, int C, int KK) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C * KK) { const int c = i / KK, t = i % KK; wT[(size_t)t * C + c] = w[i]; }
+}
+__global__ void dw_grad_from_tap_major_kernel(const float* gT, float* g, int C, int KK) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C * KK) { const int c = i / KK, t = i % KK; g[i] += gT[(size_t)t * C + c]; }
+}
+
+struct DwGeom { int B, Hi, Wi, Ho, Wo, C; };
+
+// forward: a [B,Hi,Wi,C] -> z [B,Ho,Wo,C]; fused per-channel sum / sumsq of z (bf16-rounded) for the next BN.
+// thread = (octet, strip of TW output pixels along W)
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* a, const float* wT, bf16* z, float* sums, DwGeom g,
+                                                         int items_per_block) {
+  constexpr int TW = 4, PAD = K / 2, NIN = (TW - 1) * S + K;
+  __shared__ float lds[256 * 16];
+  const CgMap m = cg_map(g.C);
+  float st[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st[i] = 0.f;
+  const int nstrip = (g.Wo + TW - 1) / TW;
+  const int nitems = g.B * g.Ho * nstrip;
+  if (m.active) {
+    const int i0 = blockIdx.x * items_per_block, i1 = min(nitems, i0 + items_per_block);
+    for (int it = i0 + m.rl; it < i1; it += m.nr) {
+      const int strip = it % nstrip, ho = (it / nstrip) % g.Ho, b = it / (nstrip * g.Ho);
+      const int wo0 = strip * TW;
+      float acc[TW][8];
+#pragma unroll
+      for (int j = 0; j < TW; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+        const int hi = ho * S - PAD + kh;
+        if (hi < 0 || hi >= g.Hi) continue;
+        float in[NIN][8];
+#pragma unroll
+        for (int x = 0; x < NIN; ++x) {
+          const int wi = wo0 * S - PAD + x;
+          if (wi >= 0 && wi < g.Wi)
+            unpack8(*reinterpret_cast<const uint4*>(a + (((size_t)b * g.Hi + hi) * g.Wi + wi) * g.C + m.cg * 8), in[x]);
+          else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) in[x][e] = 0.f;
+        }
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+          float w[8];
+          ld8f(wT + (size_t)(kh * K + kw) * g.C + m.cg * 8, w);
+#pragma unroll
+          for (int j = 0; j < TW; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[j][e] += in[j * S + kw][e] * w[e];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TW; ++j) {
+        if (wo0 + j < g.Wo) {
+          const uint4 o = pack8(acc[j]);
+          *reinterpret_cast<uint4*>(z + (((size_t)b * g.Ho + ho) * g.Wo + wo0 + j) * g.C + m.cg * 8) = o;
+          float r[8];
+          unpack8(o, r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { st[e] += r[e]; st[8 + e] += r[e] * r[e]; }
+        }
+      }
+    }
+  }
+  block_reduce_atomic<16>(st, m, lds, sums, (size_t)g.C);
+}
+
+// backward data: da[b,hi,wi,c] = sum_{kh,kw} dz[b,(hi+PAD-kh)/S,(wi+PAD-kw)/S,c] * w[kh,kw,c]   (divisible taps only)
+// fused: dpre = da * silu'(scale*z1+shift) written to `out`, and BN-backward sums (sum dpre, sum dpre*zhat) of the
+// producer's BatchNorm accumulated per channel.  thread = (octet, strip of TW input pixels along W)
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const bf16* dz, const float* wT, const bf16* z1, const float* mean,
+                                                              const float* rstd, const float* scale, const float* shift,
+                                                              const bf16* resid, bf16* out, float* sums, DwGeom g,
+                                                              int items_per_block) {
+  constexpr int TW = 4, PAD = K / 2;
+  __shared__ float lds[256 * 16];
+  const CgMap m = cg_map(g.C);
+  float st[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st[i] = 0.f;
+  const int nstrip = (g.Wi + TW - 1) / TW;
+  const int nitems = g.B * g.Hi * nstrip;
+  if (m.active) {
+    const int c0 = m.cg * 8;
+    float mu[8], rs[8], sc[8], sh[8];
+    if (z1) { ld8f(mean + c0, mu); ld8f(rstd + c0, rs); ld8f(scale + c0, sc); ld8f(shift + c0, sh); }
+    const int i0 = blockIdx.x * items_per_block, i1 = min(nitems, i0 + items_per_block);
+    for (int it = i0 + m.rl; it < i1; it += m.nr) {
+      const int strip = it % nstrip, hi = (it / nstrip) % g.Hi, b = it / (nstrip * g.Hi);
+      const int wi0 = strip * TW;
+      float acc[TW][8];
+#pragma unroll
+      for (int j = 0; j < TW; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+        const int t = hi + PAD - kh;
+        if (t < 0 || (t % S) != 0) continue;
+        const int ho = t / S;
+        if (ho >= g.Ho) continue;
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            // wi0 is a multiple of TW (and so of S): divisibility of (wi0 + j + PAD - kw) by S is a compile-time fact
+            if (((j + PAD - kw) % S + S) % S != 0) continue;
+            const int u = wi0 + j + PAD - kw;
+            if (u < 0) continue;
+            const int wo = u / S;
+            if (wo >= g.Wo) continue;
+            float d[8], w[8];
+            unpack8(*reinterpret_cast<const uint4*>(dz + (((size_t)b * g.Ho + ho) * g.Wo + wo) * g.C + c0), d);
+            ld8f(wT + (size_t)(kh * K + kw) * g.C + c0, w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[j][e] += d[e] * w[e];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TW; ++j) {
+        if (wi0 + j < g.Wi) {
+          const size_t off = (((size_t)b * g.Hi + hi) * g.Wi + wi0 + j) * g.C + c0;
+          float o[8];
+          if (z1) {
+            float zz[8];
+            unpack8(*reinterpret_cast<const uint4*>(z1 + off), zz);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = acc[j][e] * silu_grad_f(zz[e] * sc[e] + sh[e]);
+            const uint4 pk = pack8(o);
+            *reinterpret_cast<uint4*>(out + off) = pk;
+            unpack8(pk, o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { st[e] += o[e]; st[8 + e] += o[e] * (zz[e] - mu[e]) * rs[e]; }
+          } else {      // plain transposed conv (+ residual gradient): the input was not a BN+SiLU output
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = acc[j][e];
+            if (resid) {
+              float r[8];
+              unpack8(*reinterpret_cast<const uint4*>(resid + off), r);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] += r[e];
+            }
+            *reinterpret_cast<uint4*>(out + off) = pack8(o);
+          }
+        }
+      }
+    }
+  }
+  if (z1) block_reduce_atomic<16>(st, m, lds, sums, (size_t)g.C);
+}
+
+// backward weight (tap-major gT [K*K][C]): one kernel row kh per blockIdx.z; thread = (octet, output row lane)
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16* dz, const bf16* a, float* gT, DwGeom g,
+                                                                int rows_per_block) {
+  constexpr int PAD = K / 2;
+  __shared__ float lds[256 * 8 * K];
+  const CgMap m = cg_map(g.C);
+  const int kh = blockIdx.z;
+  float acc[8 * K];
+#pragma unroll
+  for (int i = 0; i < 8 * K; ++i) acc[i] = 0.f;
+  if (m.active) {
+    const int c0 = m.cg * 8;
+    const int nrows = g.B * g.Ho;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
+    for (int r = r0 + m.rl; r < r1; r += m.nr) {
+      const int ho = r % g.Ho, b = r / g.Ho;
+      const int hi = ho * S - PAD + kh;
+      if (hi < 0 || hi >= g.Hi) continue;
+      const bf16* arow = a + (((size_t)b * g.Hi + hi) * g.Wi) * g.C + c0;
+      const bf16* drow = dz + (((size_t)b * g.Ho + ho) * g.Wo) * g.C + c0;
+      for (int wo = 0; wo < g.Wo; ++wo) {
+        float d[8];
+        unpack8(*reinterpret_cast<const uint4*>(drow + (size_t)wo * g.C), d);
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+          const int wi = wo * S - PAD + kw;
+          if (wi < 0 || wi >= g.Wi) continue;
+          float x[8];
+          unpack8(*reinterpret_cast<const uint4*>(arow + (size_t)wi * g.C), x);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[kw * 8 + e] += d[e] * x[e];
+        }
+      }
+    }
+  }
+  block_reduce_atomic<8 * K>(acc, m, lds, gT + (size_t)kh * K * g.C, (size_t)g.C);
+}
+
+// ------------------------------------------------------------------ stem conv 3x3 s2 p1 on the NCHW fp32 image
+struct StemGeom { int B, Hi, Wi, Ho, Wo, Co; };
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const float* w, bf16* z, float* sums, StemGeom g,
+                                                       int pix_per_block) {
+  __shared__ float lds[256 * 16];
+  __shared__ float wl[27 * 64];              // [tap][co], Co <= 64
+  for (int i = threadIdx.x; i < 27 * g.Co; i += 256) { const int co = i / 27, t = i % 27; wl[t * g.Co + co] = w[i]; }
+  __syncthreads();
+  const CgMap m = cg_map(g.Co);
+  float st[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st[i] = 0.f;
+  const int npix = g.B * g.Ho * g.Wo;
+  if (m.active) {
+    const int c0 = m.cg * 8;
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
+    for (int p = p0 + m.rl; p < p1; p += m.nr) {
+      const int wo = p % g.Wo, ho = (p / g.Wo) % g.Ho, b = p / (g.Wo * g.Ho);
+      float acc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int hi = ho * 2 - 1 + kh;
+          if (hi < 0 || hi >= g.Hi) continue;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int wi = wo * 2 - 1 + kw;
+            if (wi < 0 || wi >= g.Wi) continue;
+            const float v = x[(((size_t)b * 3 + ci) * g.Hi + hi) * g.Wi + wi];
+            const float* wp = wl + (ci * 9 + kh * 3 + kw) * g.Co + c0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v * wp[e];
+          }
+        }
+      const uint4 o = pack8(acc);
+      *reinterpret_cast<uint4*>(z + (size_t)p * g.Co + c0) = o;
+      float r[8];
+      unpack8(o, r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { st[e] += r[e]; st[8 + e] += r[e] * r[e]; }
+    }
+  }
+  block_reduce_atomic<16>(st, m, lds, sums, (size_t)g.Co);
+}
+
+// dW[co][ci][kh][kw] += sum_p dz[p,co] * x[p @ tap]; thread = (tap, octet), loops over the block's pixel slab
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16* dz, const float* x, float* dw, StemGeom g, int pix_per_block) {
+  const int G = g.Co >> 3;
+  const int t = threadIdx.x;
+  if (t >= 27 * G) return;
+  const int tap = t / G, cg = t % G, c0 = cg * 8;
+  const int ci = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const int npix = g.B * g.Ho * g.Wo;
+  const int p0 = blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
+  for (int p = p0; p < p1; ++p) {
+    const int wo = p % g.Wo, ho = (p / g.Wo) % g.Ho, b = p / (g.Wo * g.Ho);
+    const int hi = ho * 2 - 1 + kh, wi = wo * 2 - 1 + kw;
+    if (hi < 0 || hi >= g.Hi || wi < 0 || wi >= g.Wi) continue;
+    const float v = x[(((size_t)b * 3 + ci) * g.Hi + hi) * g.Wi + wi];
+    float d[8];
+    unpack8(*reinterpret_cast<const uint4*>(dz + (size_t)p * g.Co + c0), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += v * d[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) atomicAdd(dw + (size_t)(c0 + e) * 27 + tap, acc[e]);
+}
+
+// ------------------------------------------------------------------ BatchNorm1d on fp32 [B, C] (thread per channel)
+__global__ void bn1d_fwd_kernel(const float* x, const float* gamma, const float* beta, float* y, float* mean_o, float* rstd_o,
+                                float* run_mean, float* run_var, int B, int C, float eps, float momentum, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mu, var;
+  if (training) {
+    float s = 0.f, q = 0.f;
+    for (int b = 0; b < B; ++b) { const float v = x[(size_t)b * C + c]; s += v; }
+    mu = s / B;
+    for (int b = 0; b < B; ++b) { const float d = x[(size_t)b * C + c] - mu; q += d * d; }
+    var = q / B;
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * ((float)B / fmaxf((float)B - 1.f, 1.f));
+  } else { mu = run_mean[c]; var = run_var[c]; }
+  const float rs = rsqrtf(var + eps);
+  if (mean_o) { mean_o[c] = mu; rstd_o[c] = rs; }
+  for (int b = 0; b < B; ++b) y[(size_t)b * C + c] = (x[(size_t)b * C + c] - mu) * rs * gamma[c] + beta[c];
+}
+__global__ void bn1d_bwd_kernel(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                float* dx, float* dgamma, float* dbeta, int B, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mu = mean[c], rs = rstd[c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = 0; b < B; ++b) { const float d = dy[(size_t)b * C + c]; s1 += d; s2 += d * (x[(size_t)b * C + c] - mu) * rs; }
+  dgamma[c] += s2; dbeta[c] += s1;
+  const float g = gamma[c] * rs;
+  for (int b = 0; b < B; ++b) {
+    const float zh = (x[(size_t)b * C + c] - mu) * rs;
+    dx[(size_t)b * C + c] = g * (dy[(size_t)b * C + c] - s1 / B - zh * s2 / B);
+  }
+}
+
+// elementwise helpers for the tower top
+__global__ void dropout_cast_kernel(const float* x, bf16* y, size_t n, unsigned long long seed, unsigned int stream, unsigned int thresh,
+                                    float inv_keep) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = x[i];
+  if (thresh) v = drop_keep(seed, stream, i, thresh) ? v * inv_keep : 0.f;
+  y[i] = f2bf(v);
+}
+__global__ void dropout_bwd_kernel(const float* dy, float* dx, size_t n, unsigned long long seed, unsigned int stream, unsigned int thresh,
+                                   float inv_keep) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = dy[i];
+  if (thresh) v = drop_keep(seed, stream, i, thresh) ? v * inv_keep : 0.f;
+  dx[i] = v;
+}
+// global-average-pool backward fused with the head BN+SiLU backward input: dy[b,hw,c] = dpool[b,c] / HW   (bf16)
+__global__ __launch_bounds__(256) void broadcast_pool_grad_kernel(const float* dpool, bf16* dy, int HW, int C, size_t nchunks) {
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nchunks; q += (size_t)gridDim.x * 256) {
+    const size_t el = q * 8;
+    const int c0 = (int)(el % (size_t)C);
+    const size_t b = el / ((size_t)HW * C);
+    float f[8];
+    ld8f(dpool + b * C + c0, f);
+    const float inv = 1.0f / HW;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] *= inv;
+    *reinterpret_cast<uint4*>(dy + el) = pack8(f);
+  }
+}
+
+// ================================================================= C-ABI
+#define REQ_C8(C, name) MMSIM_REQUIRE((C) > 0 && ((C) % 8) == 0, name ": channel count must be a positive multiple of 8")
+
+static int rows_per_block_for(int P, int nr) {
+  // aim for ~1024 blocks, at least nr rows each
+  int rpb = (P + 1023) / 1024;
+  if (rpb < nr) rpb = nr;
+  return rpb;
+}
+static int nr_of(int C) { const int G = C >> 3; return G >= 256 ? 1 : 256 / G; }
+
+extern "C" int mmsim_bn_stats(const void* z, float* sums, int P, int C, void* stream) {
+  MMSIM_REQUIRE(z && sums && P > 0, "bn_stats: bad arguments"); REQ_C8(C, "bn_stats");
+  const int rpb = rows_per_block_for(P, nr_of(C));
+  hipLaunchKernelGGL(bn_stats_kernel, dim3((P + rpb - 1) / rpb, cg_grid_y(C)), dim3(256), 0, (hipStream_t)stream, (const bf16*)z,
+                     sums, P, C, rpb);
+  return mmsim_check_launch("bn_stats");
+}
+
+extern "C" int mmsim_bn_finalize(const float* sums, const float* gamma, const float* beta, float* mean, float* rstd, float* scale,
+                                 float* shift, float* run_mean, float* run_var, int C, float count, float eps, float momentum,
+                                 void* stream) {
+  MMSIM_REQUIRE(sums && gamma && beta && mean && rstd && scale && shift && C > 0 && count > 0, "bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta, mean, rstd,
+                     scale, shift, run_mean, run_var, C, count, eps, momentum);
+  return mmsim_check_launch("bn_finalize");
+}
+
+extern "C" int mmsim_bn_apply(const void* z, const float* scale, const float* shift, const void* resid, void* out, int P, int C,
+                              int act_silu, void* stream) {
+  MMSIM_REQUIRE(z && scale && shift && out && P > 0, "bn_apply: bad arguments"); REQ_C8(C, "bn_apply");
+  const size_t nch = (size_t)P * C / 8;
+  size_t gsz = (nch + 255) / 256; if (gsz > 16384) gsz = 16384;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scale, shift,
+                     (const bf16*)resid, (bf16*)out, nch, C, act_silu);
+  return mmsim_check_launch("bn_apply");
+}
+
+extern "C" int mmsim_pool_bn_act(const void* z, const float* scale, const float* shift, const void* other, float* out, int B,
+                                 int HW, int C, int act_silu, float mul, void* stream) {
+  MMSIM_REQUIRE(z && scale && shift && out && B > 0 && HW > 0, "pool_bn_act: bad arguments"); REQ_C8(C, "pool_bn_act");
+  hipLaunchKernelGGL(pool_bn_act_kernel, dim3(B, cg_grid_y(C)), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scale, shift,
+                     (const bf16*)other, out, HW, C, act_silu, mul);
+  return mmsim_check_launch("pool_bn_act");
+}
+
+extern "C" int mmsim_se_mlp_fwd(const float* s, const float* w_reduce, const float* b_reduce, const float* w_expand,
+                                const float* b_expand, float* hr, float* gate, int B, int C, int RD, void* stream) {
+  MMSIM_REQUIRE(s && w_reduce && b_reduce && w_expand && b_expand && hr && gate && B > 0 && C > 0 && RD > 0, "se_mlp_fwd: bad arguments");
+  hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(B), dim3(256), (size_t)(C + RD) * 4, (hipStream_t)stream, s, w_reduce, b_reduce,
+                     w_expand, b_expand, hr, gate, C, RD);
+  return mmsim_check_launch("se_mlp_fwd");
+}
+
+extern "C" int mmsim_se_mlp_bwd(const float* dgate, const float* gate, const float* hr, const float* s, const float* w_reduce,
+                                const float* w_expand, float* dpe, float* dr, float* ds, float* dw_reduce, float* db_reduce,
+                                float* dw_expand, float* db_expand, int B, int C, int RD, void* stream) {
+  MMSIM_REQUIRE(dgate && gate && hr && s && w_reduce && w_expand && dpe && dr && ds && dw_reduce && db_reduce && dw_expand && db_expand,
+                "se_mlp_bwd: null operand");
+  hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B), dim3(256), (size_t)(C + RD) * 4, (hipStream_t)stream, dgate, gate, hr, w_reduce,
+                     w_expand, dpe, dr, ds, C, RD);
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * RD + 255) / 256), dim3(256), 0, (hipStream_t)stream, dpe, dr, hr, s, dw_reduce,
+                     db_reduce, dw_expand, db_expand, B, C, RD);
+  return mmsim_check_launch("se_mlp_bwd");
+}
+
+static BnBwd mk_bnbwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* scale, const float* shift,
+                      const float* gate, const float* dsq, int hw, int act, int P, int C) {
+  BnBwd p;
+  p.dy = (const bf16*)dy; p.z = (const bf16*)z; p.mean = mean; p.rstd = rstd; p.scale = scale; p.shift = shift;
+  p.gate = gate; p.dsq = dsq; p.hw = hw > 0 ? hw : 1; p.act = act; p.P = P; p.C = C; p.inv_hw = 1.0f / (float)(hw > 0 ? hw : 1);
+  return p;
+}
+
+/* sums [2][C] must be zero on entry */
+extern "C" int mmsim_bn_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* scale,
+                            const float* shift, const float* gate, const float* dsq, int hw, int act_silu, float* sums,
+                            int sums_ready, void* dz, float* dgamma, float* dbeta, int P, int C, void* stream) {
+  MMSIM_REQUIRE(dy && z && mean && rstd && scale && shift && sums && dz && P > 0, "bn_bwd: bad arguments"); REQ_C8(C, "bn_bwd");
+  MMSIM_REQUIRE((gate == nullptr) == (dsq == nullptr), "bn_bwd: gate and dsq come together");
+  const BnBwd p = mk_bnbwd(dy, z, mean, rstd, scale, shift, gate, dsq, hw, act_silu, P, C);
+  const int rpb = rows_per_block_for(P, nr_of(C));
+  dim3 grid((P + rpb - 1) / rpb, cg_grid_y(C));
+  if (!sums_ready) hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, sums, rpb);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, sums, (bf16*)dz, dgamma, dbeta, rpb);
+  return mmsim_check_launch("bn_bwd");
+}
+
+extern "C" int mmsim_dw_weight_to_tap_major(const float* w, float* wT, int C, int K, void* stream) {
+  MMSIM_REQUIRE(w && wT && C > 0 && (K == 3 || K == 5), "dw_weight_to_tap_major: bad arguments");
+  hipLaunchKernelGGL(dw_weight_to_tap_major_kernel, dim3((C * K * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, wT, C, K * K);
+  return mmsim_check_launch("dw_weight_to_tap_major");
+}
+extern "C" int mmsim_dw_grad_from_tap_major(const float* gT, float* g, int C, int K, void* stream) {
+  MMSIM_REQUIRE(gT && g && C > 0 && (K == 3 || K == 5), "dw_grad_from_tap_major: bad arguments");
+  hipLaunchKernelGGL(dw_grad_from_tap_major_kernel, dim3((C * K * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, gT, g, C, K * K);
+  return mmsim_check_launch("dw_grad_from_tap_major");
+}
+
+static int dw_check(int B, int Hi, int Wi, int C, int K, int S, DwGeom* g) {
+  MMSIM_REQUIRE(B > 0 && Hi > 0 && Wi > 0, "dwconv: bad geometry"); REQ_C8(C, "dwconv");
+  MMSIM_REQUIRE((K == 3 || K == 5) && (S == 1 || S == 2), "dwconv: kernel 3/5 and stride 1/2 only");
+  g->B = B; g->Hi = Hi; g->Wi = Wi; g->C = C;
+  g->Ho = (Hi + 2 * (K / 2) - K) / S + 1; g->Wo = (Wi + 2 * (K / 2) - K) / S + 1;
+  return MMSIM_OK;
+}
+#define DW_DISPATCH(KERNEL, ...)                                                                       \
+  if (K == 3 && S == 1) hipLaunchKernelGGL((KERNEL<3, 1>), __VA_ARGS__);                               \
+  else if (K == 3 && S == 2) hipLaunchKernelGGL((KERNEL<3, 2>), __VA_ARGS__);                          \
+  else if (K == 5 && S == 1) hipLaunchKernelGGL((KERNEL<5, 1>), __VA_ARGS__);                          \
+  else hipLaunchKernelGGL((KERNEL<5, 2>), __VA_ARGS__);
+
+extern "C" int mmsim_dwconv_fwd(const void* a, const float* w_tap_major, void* z, float* sums, int B, int Hi, int Wi, int C, int K,
+                                int S, void* stream) {
+  DwGeom g; int rc = dw_check(B, Hi, Wi, C, K, S, &g); if (rc) return rc;
+  MMSIM_REQUIRE(a && w_tap_major && z && sums, "dwconv_fwd: null operand");
+  const int nitems = B * g.Ho * ((g.Wo + 3) / 4);
+  const int ipb = rows_per_block_for(nitems, nr_of(C));
+  dim3 grid((nitems + ipb - 1) / ipb, cg_grid_y(C));
+  DW_DISPATCH(dwconv_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)a, w_tap_major, (bf16*)z, sums, g, ipb)
+  return mmsim_check_launch("dwconv_fwd");
+}
+
+extern "C" int mmsim_dwconv_bwd_data(const void* dz, const float* w_tap_major, const void* z1, const float* mean, const float* rstd,
+                                     const float* scale, const float* shift, const void* resid, void* dpre, float* sums, int B,
+                                     int Hi, int Wi, int C, int K, int S, void* stream) {
+  DwGeom g; int rc = dw_check(B, Hi, Wi, C, K, S, &g); if (rc) return rc;
+  MMSIM_REQUIRE(dz && w_tap_major && dpre, "dwconv_bwd_data: null operand");
+  MMSIM_REQUIRE(!z1 || (mean && rstd && scale && shift && sums), "dwconv_bwd_data: fused BN+SiLU backward needs the BN state");
+  MMSIM_REQUIRE(!(z1 && resid), "dwconv_bwd_data: resid only in the plain (z1 == NULL) form");
+  const int nitems = B * Hi * ((Wi + 3) / 4);
+  const int ipb = rows_per_block_for(nitems, nr_of(C));
+  dim3 grid((nitems + ipb - 1) / ipb, cg_grid_y(C));
+  DW_DISPATCH(dwconv_bwd_data_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, w_tap_major, (const bf16*)z1, mean,
+              rstd, scale, shift, (const bf16*)resid, (bf16*)dpre, sums, g, ipb)
+  return mmsim_check_launch("dwconv_bwd_data");
+}
+
+extern "C" int mmsim_dwconv_bwd_weight(const void* dz, const void* a, float* g_tap_major, int B, int Hi, int Wi, int C, int K, int S,
+                                       void* stream) {
+  DwGeom g; int rc = dw_check(B, Hi, Wi, C, K, S, &g); if (rc) return rc;
+  MMSIM_REQUIRE(dz && a && g_tap_major, "dwconv_bwd_weight: null operand");
+  const int nrows = B * g.Ho;
+  int rpb = (nrows + 255) / 256; const int nr = nr_of(C); if (rpb < nr) rpb = nr;
+  dim3 grid((nrows + rpb - 1) / rpb, cg_grid_y(C), K);
+  DW_DISPATCH(dwconv_bwd_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, (const bf16*)a, g_tap_major, g, rpb)
+  return mmsim_check_launch("dwconv_bwd_weight");
+}
+
+extern "C" int mmsim_stem_fwd(const float* x, const float* w, void* z, float* sums, int B, int Hi, int Wi, int Co, void* stream) {
+  MMSIM_REQUIRE(x && w && z && sums && B > 0 && Hi > 1 && Wi > 1, "stem_fwd: bad arguments"); REQ_C8(Co, "stem_fwd");
+  MMSIM_REQUIRE(Co <= 64, "stem_fwd: at most 64 output channels");
+  StemGeom g; g.B = B; g.Hi = Hi; g.Wi = Wi; g.Ho = (Hi + 2 - 3) / 2 + 1; g.Wo = (Wi + 2 - 3) / 2 + 1; g.Co = Co;
+  const int npix = B * g.Ho * g.Wo;
+  const int ppb = rows_per_block_for(npix, nr_of(Co));
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3((npix + ppb - 1) / ppb), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)z, sums, g, ppb);
+  return mmsim_check_launch("stem_fwd");
+}
+
+extern "C" int mmsim_stem_wgrad(const void* dz, const float* x, float* dw, int B, int Hi, int Wi, int Co, void* stream) {
+  MMSIM_REQUIRE(dz && x && dw && B > 0, "stem_wgrad: bad arguments"); REQ_C8(Co, "stem_wgrad");
+  MMSIM_REQUIRE(27 * (Co / 8) <= 256, "stem_wgrad: at most 72 output channels");
+  StemGeom g; g.B = B; g.Hi = Hi; g.Wi = Wi; g.Ho = (Hi + 2 - 3) / 2 + 1; g.Wo = (Wi + 2 - 3) / 2 + 1; g.Co = Co;
+  const int npix = B * g.Ho * g.Wo;
+  const int ppb = 2048;
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3((npix + ppb - 1) / ppb), dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, x, dw, g, ppb);
+  return mmsim_check_launch("stem_wgrad");
+}
+
+extern "C" int mmsim_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                              float* run_mean, float* run_var, int B, int C, float eps, float momentum, int training, void* stream) {
+  MMSIM_REQUIRE(x && gamma && beta && y && run_mean && run_var && B > 0 && C > 0, "bn1d_fwd: bad arguments");
+  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, run_mean,
+                     run_var, B, C, eps, momentum, training);
+  return mmsim_check_launch("bn1d_fwd");
+}
+extern "C" int mmsim_bn1d_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx,
+                              float* dgamma, float* dbeta, int B, int C, void* stream) {
+  MMSIM_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && B > 0 && C > 0, "bn1d_bwd: bad arguments");
+  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dx, dgamma,
+                     dbeta, B, C);
+  return mmsim_check_launch("bn1d_bwd");
+}
+
+extern "C" int mmsim_dropout_cast(const float* x, void* y_bf16, unsigned long long n, float p, unsigned long long seed,
+                                  unsigned int stream_id, void* stream) {
+  MMSIM_REQUIRE(x && y_bf16 && p >= 0.f && p < 1.f, "dropout_cast: bad arguments");
+  if (n == 0) return MMSIM_OK;
+  hipLaunchKernelGGL(dropout_cast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)y_bf16,
+                     (size_t)n, seed, stream_id, p > 0.f ? (unsigned int)((double)p * 4294967296.0) : 0u, 1.0f / (1.0f - p));
+  return mmsim_check_launch("dropout_cast");
+}
+extern "C" int mmsim_dropout_bwd(const float* dy, float* dx, unsigned long long n, float p, unsigned long long seed,
+                                 unsigned int stream_id, void* stream) {
+  MMSIM_REQUIRE(dy && dx && p >= 0.f && p < 1.f, "dropout_bwd: bad arguments");
+  if (n == 0) return MMSIM_OK;
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, (size_t)n, seed,
+                     stream_id, p > 0.f ? (unsigned int)((double)p * 4294967296.0) : 0u, 1.0f / (1.0f - p));
+  return mmsim_check_launch("dropout_bwd");
+}
+extern "C" int mmsim_broadcast_pool_grad(const float* dpool, void* dy, int B, int HW, int C, void* stream) {
+  MMSIM_REQUIRE(dpool && dy && B > 0 && HW > 0, "broadcast_pool_grad: bad arguments"); REQ_C8(C, "broadcast_pool_grad");
+  const size_t nch = (size_t)B * HW * C / 8;
+  size_t gsz = (nch + 255) / 256; if (gsz > 16384) gsz = 16384;
+  hipLaunchKernelGGL(broadcast_pool_grad_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, dpool, (bf16*)dy, HW, C, nch);
+  return mmsim_check_launch("broadcast_pool_grad");
+}

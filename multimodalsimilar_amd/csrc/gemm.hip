@@ -28,6 +28,8 @@ struct GemmParams {
   int M, N, K, lda, ldb, ldc, ld_aux;
   int c_f32, epi, atomic, accum, k_per_split, tiles_m, tiles_n;
   float alpha;
+  // optional operand transform (1x1 conv after BN + SiLU + squeeze-excite): x -> silu(scale[c] x + shift[c]) * gate[b, c]
+  const float* xf_scale; const float* xf_shift; const float* xf_gate; int xf_hw, xf_C;
 };
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_MUL_GELU_GRAD = 2, EPI_ADD = 3, EPI_TANH = 4 };
@@ -70,6 +72,36 @@ __device__ __forceinline__ void store_tile(char* lds, int tid, const uint4 (&reg
   }
 }
 
+// BN-affine + SiLU (+ SE gate) applied to a staged tile in registers.  The "pixel" index is the row of a
+// k-major operand / the k index of a transposed one; the channel index is the other one.
+template <bool TRANS>
+__device__ __forceinline__ void xform_tile(const GemmParams& p, int r0, int R, int k0, int kend, int tid, uint4 (&reg)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    int pix, ch;
+    bool ok;
+    if (!TRANS) { pix = r0 + (c >> 3); ch = k0 + (c & 7) * 8; ok = pix < R && ch < kend; }
+    else { pix = k0 + (c >> 4); ch = r0 + (c & 15) * 8; ok = pix < kend && ch < R; }
+    if (!ok) continue;
+    const bf8 v = __builtin_bit_cast(bf8, reg[i]);
+    const float4 s0 = *reinterpret_cast<const float4*>(p.xf_scale + ch), s1 = *reinterpret_cast<const float4*>(p.xf_scale + ch + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(p.xf_shift + ch), h1 = *reinterpret_cast<const float4*>(p.xf_shift + ch + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    float g[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (p.xf_gate) {
+      const float* gp = p.xf_gate + (size_t)(pix / p.xf_hw) * p.xf_C + ch;
+      const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+      g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+    }
+    bf8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(silu_f(bf2f(v[e]) * sc[e] + sh[e]) * g[e]);
+    reg[i] = __builtin_bit_cast(uint4, o);
+  }
+}
+
 // fragment of 16 "rows" (row index = lane&15) x 32 k for k-step ks, rows starting at rbase (multiple of 16)
 template <bool TRANS>
 __device__ __forceinline__ bf8 read_frag(const char* lds, int rbase, int ks, int lane) {
@@ -91,7 +123,7 @@ __device__ __forceinline__ bf8 read_frag(const char* lds, int rbase, int ks, int
   }
 }
 
-template <bool TA, bool TB_KMAJOR>
+template <bool TA, bool TB_KMAJOR, int XF = 0>   // XF: 0 none, 1 transform A, 2 transform B
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -117,6 +149,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   uint4 ra[4], rb[4];
   load_tile<TA>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
   load_tile<!TB_KMAJOR>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb);
+  if (XF == 1) xform_tile<TA>(p, m0, p.M, kbeg, kend, tid, ra);
+  if (XF == 2) xform_tile<!TB_KMAJOR>(p, n0, p.N, kbeg, kend, tid, rb);
   store_tile<TA>(smem, tid, ra);
   store_tile<!TB_KMAJOR>(smem + OP_STAGE_BYTES, tid, rb);
   __syncthreads();
@@ -143,6 +177,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
     if (t + 1 < nk) {
+      if (XF == 1) xform_tile<TA>(p, m0, p.M, kbeg + (t + 1) * BK, kend, tid, ra);
+      if (XF == 2) xform_tile<!TB_KMAJOR>(p, n0, p.N, kbeg + (t + 1) * BK, kend, tid, rb);
       char* na = smem + (cur ^ 1) * STAGE_BYTES;
       store_tile<TA>(na, tid, ra);
       store_tile<!TB_KMAJOR>(na + OP_STAGE_BYTES, tid, rb);
@@ -224,10 +260,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 }
 
 // C-ABI -- see include/mmsim_hip.h for the contract.
-extern "C" int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B,
-                               int ldb, void* C, int ldc, int c_is_f32, const float* bias, int epilogue,
-                               const void* aux_in, void* aux_out, int ld_aux, float alpha, int split_k,
-                               int accumulate, void* stream) {
+static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B,
+                     int ldb, void* C, int ldc, int c_is_f32, const float* bias, int epilogue,
+                     const void* aux_in, void* aux_out, int ld_aux, float alpha, int split_k,
+                     int accumulate, int xf_operand, const float* xf_scale, const float* xf_shift, const float* xf_gate,
+                     int xf_hw, void* stream) {
   MMSIM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: M, N, K must be positive");
   MMSIM_REQUIRE(A && B && C, "gemm: null operand");
   MMSIM_REQUIRE((lda % 8) == 0 && (ldb % 8) == 0, "gemm: lda/ldb must be multiples of 8 elements (16-byte rows)");
@@ -249,6 +286,8 @@ extern "C" int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, c
   p.aux_in = (const bf16*)aux_in; p.aux_out = (bf16*)aux_out;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux;
   p.c_f32 = c_is_f32; p.epi = epilogue; p.atomic = split_k > 1; p.accum = accumulate; p.alpha = alpha;
+  p.xf_scale = xf_scale; p.xf_shift = xf_shift; p.xf_gate = xf_gate; p.xf_hw = xf_hw > 0 ? xf_hw : 1;
+  p.xf_C = (xf_operand == 1) ? K : N;
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
   int kps = (K + split_k - 1) / split_k;
   kps = ((kps + BK - 1) / BK) * BK;
@@ -263,9 +302,15 @@ extern "C" int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, c
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  if (!trans_a && b_kmajor) {
+  if (xf_operand == 1) {
+    hipLaunchKernelGGL((gemm_bf16_kernel<false, true, 1>), grid, block, lds, s, p);
+  } else if (xf_operand == 2) {
+    hipLaunchKernelGGL((gemm_bf16_kernel<true, false, 2>), grid, block, lds, s, p);
+  } else if (!trans_a && b_kmajor) {
     hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, lds, s, p);
   } else if (!trans_a && !b_kmajor) {
     hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, lds, s, p);
@@ -275,4 +320,25 @@ extern "C" int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, c
     hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, lds, s, p);
   }
   return mmsim_check_launch("gemm_bf16");
+}
+
+extern "C" int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B,
+                               int ldb, void* C, int ldc, int c_is_f32, const float* bias, int epilogue,
+                               const void* aux_in, void* aux_out, int ld_aux, float alpha, int split_k,
+                               int accumulate, void* stream) {
+  return gemm_impl(trans_a, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, c_is_f32, bias, epilogue, aux_in, aux_out, ld_aux,
+                   alpha, split_k, accumulate, 0, nullptr, nullptr, nullptr, 1, stream);
+}
+
+// 1x1 conv whose input is silu(scale*z + shift) * gate[pixel / hw, channel] applied on the fly while staging:
+//   xf_operand = 1: forward   C[P, Cout] = xf(A)[P, Cin] * B[Cout, Cin]^T        (A k-major, B k-major)
+//   xf_operand = 2: wgrad     C[Cout, Cin] (+)= A[P, Cout]^T * xf(B)[P, Cin]      (both stored [P][.])
+extern "C" int mmsim_gemm_bf16_xf(int xf_operand, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                                  void* C, int ldc, int c_is_f32, const float* xf_scale, const float* xf_shift,
+                                  const float* xf_gate, int xf_hw, int split_k, int accumulate, void* stream) {
+  MMSIM_REQUIRE(xf_operand == 1 || xf_operand == 2, "gemm_xf: xf_operand must be 1 (A, forward) or 2 (B, wgrad)");
+  MMSIM_REQUIRE(xf_scale && xf_shift, "gemm_xf: scale/shift required");
+  MMSIM_REQUIRE(((xf_operand == 1 ? K : N) % 8) == 0, "gemm_xf: transformed channel count must be a multiple of 8");
+  return gemm_impl(xf_operand == 2, xf_operand == 1, M, N, K, A, lda, B, ldb, C, ldc, c_is_f32, nullptr, 0, nullptr, nullptr, 0,
+                   1.0f, split_k, accumulate, xf_operand, xf_scale, xf_shift, xf_gate, xf_hw, stream);
 }

@@ -1,0 +1,76 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL all-reduce over xGMI of the flat gradient buffers.
+
+The reference has no torch.distributed path (only single-process nn.DataParallel in two scripts);
+the contract kept is its semantics: the update is the gradient of the GLOBAL-batch mean loss, BatchNorm statistics
+stay per replica.  Each rank computes grad of its local mean loss; gradients are SUMMED across ranks and the
+1/world factor is folded into the fused AdamW kernel (grad_scale).
+xGMI is point-to-point (per-link bound), so messages are few and large: gradient ranges are reported by the towers
+as their backward finishes them (``grad_ready_hook``), coalesced into >= ``bucket_bytes`` contiguous slices of the
+flat buffer, and all-reduced asynchronously (RCCL runs them on its own stream, overlapped with the rest of backward).
+"""
+import torch
+import torch.distributed as dist
+
+from .optim import collect_flat_buffers
+
+
+class GradientExchange:
+    def __init__(self, modules, bucket_bytes=64 << 20, process_group=None):
+        self.flats = collect_flat_buffers(modules)
+        self.bucket_bytes = bucket_bytes
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._pending = {}      # id(flat) -> [start, end) waiting to be sent
+        self._handles = []
+        self._sent = {}         # id(flat) -> list of (start, end) already all-reduced this step
+        roots = [modules] if isinstance(modules, torch.nn.Module) else list(modules)
+        for root in roots:
+            for m in root.modules():
+                if hasattr(m, "grad_ready_hook") and hasattr(m, "flat_buffers"):
+                    m.grad_ready_hook = self._on_ready
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
+
+    def _launch(self, flat, start, end):
+        if self.world == 1 or end <= start:
+            return
+        h = dist.all_reduce(flat.grad[start:end], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._handles.append(h)
+        self._sent.setdefault(id(flat), []).append((start, end))
+
+    def _on_ready(self, flat, start, end):
+        """Called from a tower's backward when flat.grad[start:end] is final."""
+        if self.world == 1:
+            return
+        cur = self._pending.get(id(flat))
+        if cur is not None and (cur[1] == start or cur[0] == end):      # contiguous with the pending range: merge
+            cur = [min(cur[0], start), max(cur[1], end)]
+        else:
+            if cur is not None:
+                self._launch(flat, cur[0], cur[1])
+            cur = [start, end]
+        if (cur[1] - cur[0]) * 4 >= self.bucket_bytes:
+            self._launch(flat, cur[0], cur[1])
+            cur = None
+        self._pending[id(flat)] = cur
+
+    def finish(self):
+        """After loss.backward(): send whatever was not reported through hooks, then wait for everything."""
+        if self.world > 1:
+            for f in self.flats:
+                cur = self._pending.get(id(f))
+                if cur is not None:
+                    self._launch(f, cur[0], cur[1])
+                if f.grad is None:
+                    continue
+                covered = sorted(self._sent.get(id(f), []))
+                pos = 0
+                for s, e in covered + [(f.total, f.total)]:
+                    if s > pos:
+                        self._launch(f, pos, s)       # gaps: ranges no hook reported
+                    pos = max(pos, e)
+            for h in self._handles:
+                h.wait()
+        self._handles, self._pending, self._sent = [], {}, {}

@@ -1,0 +1,452 @@
+"""MI355X-native EfficientNet image tower (the arithmetic of timm ``efficientnet_b0`` / ``efficientnet_b4`` that
+cv_classifier.py:23-27,49 calls; architecture per SURVEY.md Appendix C).
+
+Host-side schedule over the HIP kernels in csrc/conv.hip and csrc/gemm.hip.  Activations are NHWC bf16 so a 1x1
+conv is a GEMM over [pixels, channels]; every BatchNorm is train-mode (batch statistics); the BN+SiLU(+SE gate)
+that precedes the projection conv is applied while that GEMM stages its operand, so the widest tensors are
+written once and never re-materialised activated.  Parameter names / shapes are timm's, so state dicts
+interchange; all parameters live in one flat buffer (fp32 master, fp32 grad, bf16 shadow).
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .flat import FlatBuffer
+from ._lib import MmsimError, lib
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+_BASE = [("ds", 1, 3, 1, 1, 16), ("ir", 2, 3, 2, 6, 24), ("ir", 2, 5, 2, 6, 40), ("ir", 3, 3, 2, 6, 80),
+         ("ir", 3, 5, 1, 6, 112), ("ir", 4, 5, 2, 6, 192), ("ir", 1, 3, 1, 6, 320)]
+_SCALE = {"efficientnet_b0": (1.0, 1.0), "efficientnet_b4": (1.4, 1.8)}
+
+
+def _make_divisible(v, divisor=8, round_limit=0.9):
+    new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    if new_v < round_limit * v:
+        new_v += divisor
+    return new_v
+
+
+def build_arch(model_name):
+    if model_name.startswith("tf_"):
+        model_name = model_name[3:]     # the scripts only ever build the non-tf variant
+    if model_name not in _SCALE:
+        raise ValueError(f"unsupported image tower {model_name!r} (efficientnet_b0 / efficientnet_b4)")
+    w, d = _SCALE[model_name]
+    stem, head = _make_divisible(32 * w), _make_divisible(1280 * w)
+    blocks, cin = [], stem
+    for si, (typ, r, k, s, e, c) in enumerate(_BASE):
+        cout = _make_divisible(c * w)
+        for bi in range(int(math.ceil(r * d))):
+            stride = s if bi == 0 else 1
+            blocks.append(SimpleNamespace(type=typ, cin=cin, mid=cin * e, cout=cout, k=k, stride=stride,
+                                          rd=int(round(cin * 0.25)), skip=(stride == 1 and cin == cout),
+                                          name=f"blocks.{si}.{bi}"))
+            cin = cout
+    return SimpleNamespace(stem=stem, head=head, blocks=blocks, last=cin)
+
+
+class _Holder(nn.Module):
+    pass
+
+
+def _node(root, dotted):
+    mod = root
+    for p in dotted.split("."):
+        if p not in mod._modules:
+            mod.add_module(p, _Holder())
+        mod = mod._modules[p]
+    return mod
+
+
+def _bn_names(b):
+    """(expand BN or None, depthwise BN, project BN) attribute names inside a block."""
+    return (None, "bn1", "bn2") if b.type == "ds" else ("bn1", "bn2", "bn3")
+
+
+class EfficientNet(nn.Module):
+    """Backbone with timm's attribute names.  ``num_features`` = head width (1280 / 1792)."""
+
+    def __init__(self, model_name="efficientnet_b4", seed=None, device=None):
+        super().__init__()
+        self.model_name = model_name
+        a = self.arch = build_arch(model_name)
+        self.num_features = a.head
+        specs, bns = [], []
+
+        def conv(name, shape):
+            specs.append((name + ".weight", shape))
+
+        def bn(name, c):
+            specs.append((name + ".weight", (c,)))
+            specs.append((name + ".bias", (c,)))
+            bns.append((name, c))
+
+        conv("conv_stem", (a.stem, 3, 3, 3)); bn("bn1", a.stem)
+        for b in a.blocks:
+            n = b.name
+            e_bn, d_bn, p_bn = _bn_names(b)
+            if b.type == "ir":
+                conv(n + ".conv_pw", (b.mid, b.cin, 1, 1)); bn(n + "." + e_bn, b.mid)
+            conv(n + ".conv_dw", (b.mid, 1, b.k, b.k)); bn(n + "." + d_bn, b.mid)
+            specs.append((n + ".se.conv_reduce.weight", (b.rd, b.mid, 1, 1)))
+            specs.append((n + ".se.conv_reduce.bias", (b.rd,)))
+            specs.append((n + ".se.conv_expand.weight", (b.mid, b.rd, 1, 1)))
+            specs.append((n + ".se.conv_expand.bias", (b.mid,)))
+            conv(n + (".conv_pw" if b.type == "ds" else ".conv_pwl"), (b.cout, b.mid, 1, 1)); bn(n + "." + p_bn, b.cout)
+        conv("conv_head", (a.head, a.last, 1, 1)); bn("bn2", a.head)
+        self._bn_list = bns
+        self._flat = FlatBuffer(specs, device="cpu")
+        self._init_weights(seed)
+        for name, _ in specs:
+            path, leaf = name.rsplit(".", 1)
+            _node(self, path).register_parameter(leaf, nn.Parameter(self._flat.view(name)))
+        # BatchNorm running statistics: views of one buffer each, so a step touches them with O(1) torch calls
+        self._bn_off, off = {}, 0
+        for n, c in bns:
+            self._bn_off[n] = off
+            off += c
+        self._bn_total = off
+        self._run = torch.cat([torch.zeros(off), torch.ones(off)])           # [mean | var]
+        self._nbt = torch.zeros(len(bns), dtype=torch.long)
+        for i, (n, c) in enumerate(bns):
+            node = _node(self, n)
+            o = self._bn_off[n]
+            node.register_buffer("running_mean", self._run[o:o + c])
+            node.register_buffer("running_var", self._run[off + o:off + o + c])
+            node.register_buffer("num_batches_tracked", self._nbt[i])
+        self._anchor = torch.zeros((), requires_grad=True)
+        self._scratch = {}
+        self._step_seed = 0
+        self.grad_ready_hook = None
+        if device is not None:
+            self.to(device)
+
+    # ------------------------------------------------------------------ parameters / buffers
+    def _init_weights(self, seed):
+        g = torch.Generator().manual_seed(seed) if seed is not None else None
+        for n in self._flat.names:
+            v = self._flat.view(n)
+            if v.dim() == 4:                      # timm efficientnet init: normal(0, sqrt(2 / fan_out))
+                cout, cin_g, kh, kw = v.shape
+                groups = cout if (cin_g == 1 and "conv_dw" in n) else 1
+                fan_out = kh * kw * cout // groups
+                v.copy_(torch.randn(v.shape, generator=g) * math.sqrt(2.0 / fan_out))
+            elif n.endswith(".weight"):           # BN gamma
+                v.fill_(1.0)
+            else:
+                v.zero_()
+
+    def _rebind(self):
+        named = dict(self.named_parameters())
+        for n in self._flat.names:
+            p = named[n]
+            p.data = self._flat.view(n)
+            p.grad = None
+        off = self._bn_total
+        for i, (n, c) in enumerate(self._bn_list):
+            node = _node(self, n)
+            o = self._bn_off[n]
+            node._buffers["running_mean"] = self._run[o:o + c]
+            node._buffers["running_var"] = self._run[off + o:off + o + c]
+            node._buffers["num_batches_tracked"] = self._nbt[i]
+
+    def _apply(self, fn, recurse=True):
+        self._flat.apply_(fn)
+        self._run = fn(self._run)
+        self._nbt = fn(self._nbt)
+        self._anchor = fn(self._anchor.detach()).requires_grad_(True)
+        self._rebind()
+        self._scratch = {}
+        return self
+
+    def _bind_grads(self):
+        self._flat.ensure_device_state()
+        named = dict(self.named_parameters())
+        for n in self._flat.names:
+            p = named[n]
+            if p.grad is None or p.grad.data_ptr() != self._flat.gview(n).data_ptr():
+                p.grad = self._flat.gview(n)
+
+    def flat_buffers(self):
+        return [self._flat]
+
+    def sync_weights(self):
+        self._flat.sync_shadow(force=True)
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self._flat._shadow_version = None
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_scratch"] = {}
+        st["grad_ready_hook"] = None
+        return st
+
+    def _buf(self, key, shape, dtype, zero=False):
+        k = (key, tuple(shape), dtype)
+        t = self._scratch.get(k)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self._flat.master.device)
+            self._scratch[k] = t
+        return t
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        """timm-style feature map [B, head, H/32, W/32] (fp32, NCHW).  CvClassifier uses forward_pooled instead."""
+        raise NotImplementedError("use forward_pooled(): the un-pooled activated head feature map is never "
+                                  "materialised on the HIP path (global pool is fused into the head BN+SiLU)")
+
+    def forward_pooled(self, x):
+        """AdaptiveAvgPool2d(1)(backbone(x)).view(B,-1) -> fp32 [B, num_features]  (cv_classifier.py:49-50)."""
+        if not x.is_cuda:
+            raise MmsimError("EfficientNet: inputs must be on the GPU; the HIP path has no CPU fallback")
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError("EfficientNet: expected an NCHW image batch [B,3,H,W] with H, W multiples of 32")
+        if not self.training:
+            raise NotImplementedError("eval-mode (running-statistics) BatchNorm path is not built yet on the HIP side")
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if need_grad:
+            return _EffFn.apply(self._anchor, self, x)
+        st = self._run_forward(x)
+        return st.pooled.clone()
+
+    def _bnp(self, st, name, i):
+        """per-BN fp32 scratch row i of (mean, rstd, scale, shift)."""
+        o, c = self._bn_off[name], dict(self._bn_list)[name]
+        return st.bnstat[i, o:o + c]
+
+    def _bn_finalize(self, st, name, sums, count):
+        fl, s = self._flat, ops._stream()
+        o, c = self._bn_off[name], sums.numel() // 2
+        lib.bn_finalize(sums.data_ptr(), fl.view(name + ".weight").data_ptr(), fl.view(name + ".bias").data_ptr(),
+                        self._bnp(st, name, 0).data_ptr(), self._bnp(st, name, 1).data_ptr(),
+                        self._bnp(st, name, 2).data_ptr(), self._bnp(st, name, 3).data_ptr(),
+                        self._run[o:o + c].data_ptr(), self._run[self._bn_total + o:self._bn_total + o + c].data_ptr(),
+                        c, float(count), BN_EPS, BN_MOMENTUM, s)
+
+    def _sums(self, st, name, which):
+        o, c = self._bn_off[name], dict(self._bn_list)[name]
+        buf = st.sums_f if which == "f" else st.sums_b
+        return buf[2 * o:2 * o + 2 * c]
+
+    def _block_fwd(self, st, b, cur, H, W):
+        """One MBConv block: (expand 1x1 -> BN -> SiLU) -> depthwise -> BN -> SiLU -> SE -> project 1x1 -> BN (+skip)."""
+        fl, s = self._flat, ops._stream()
+        B, dev, bf = st.B, cur.device, torch.bfloat16
+        E = lambda *sh, dt=bf: torch.empty(*sh, dtype=dt, device=dev)
+        V, SV = fl.view, fl.sview
+        n = b.name
+        e_bn, d_bn, p_bn = _bn_names(b)
+        bs = SimpleNamespace(x_in=cur, H=H, W=W)
+        P_in = B * H * W
+        if b.type == "ir":
+            bs.z1 = E(P_in, b.mid)
+            ops.gemm(cur, SV(n + ".conv_pw.weight", (b.mid, b.cin)), bs.z1)
+            sm = self._sums(st, n + "." + e_bn, "f")
+            lib.bn_stats(bs.z1.data_ptr(), sm.data_ptr(), P_in, b.mid, s)
+            self._bn_finalize(st, n + "." + e_bn, sm, P_in)
+            bs.a1 = E(P_in, b.mid)
+            lib.bn_apply(bs.z1.data_ptr(), self._bnp(st, n + "." + e_bn, 2).data_ptr(),
+                         self._bnp(st, n + "." + e_bn, 3).data_ptr(), None, bs.a1.data_ptr(), P_in, b.mid, 1, s)
+        else:
+            bs.a1 = cur
+        Ho, Wo = (H + b.stride - 1) // b.stride, (W + b.stride - 1) // b.stride
+        P_out = B * Ho * Wo
+        bs.wT = E(b.k * b.k, b.mid, dt=torch.float32)
+        lib.dw_weight_to_tap_major(V(n + ".conv_dw.weight").data_ptr(), bs.wT.data_ptr(), b.mid, b.k, s)
+        bs.z2 = E(P_out, b.mid)
+        sm = self._sums(st, n + "." + d_bn, "f")
+        lib.dwconv_fwd(bs.a1.data_ptr(), bs.wT.data_ptr(), bs.z2.data_ptr(), sm.data_ptr(), B, H, W, b.mid, b.k, b.stride, s)
+        self._bn_finalize(st, n + "." + d_bn, sm, P_out)
+        sc2, sh2 = self._bnp(st, n + "." + d_bn, 2), self._bnp(st, n + "." + d_bn, 3)
+        bs.s = E(B, b.mid, dt=torch.float32)
+        lib.pool_bn_act(bs.z2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), None, bs.s.data_ptr(), B, Ho * Wo, b.mid, 1,
+                        1.0 / (Ho * Wo), s)
+        bs.hr = E(B, b.rd, dt=torch.float32)
+        bs.gate = E(B, b.mid, dt=torch.float32)
+        lib.se_mlp_fwd(bs.s.data_ptr(), V(n + ".se.conv_reduce.weight").data_ptr(), V(n + ".se.conv_reduce.bias").data_ptr(),
+                       V(n + ".se.conv_expand.weight").data_ptr(), V(n + ".se.conv_expand.bias").data_ptr(),
+                       bs.hr.data_ptr(), bs.gate.data_ptr(), B, b.mid, b.rd, s)
+        pw = n + (".conv_pw" if b.type == "ds" else ".conv_pwl")
+        bs.z3 = E(P_out, b.cout)
+        w3 = SV(pw + ".weight", (b.cout, b.mid))
+        lib.gemm_bf16_xf(1, P_out, b.cout, b.mid, bs.z2.data_ptr(), b.mid, w3.data_ptr(), b.mid, bs.z3.data_ptr(), b.cout, 0,
+                         sc2.data_ptr(), sh2.data_ptr(), bs.gate.data_ptr(), Ho * Wo, 1, 0, s)
+        sm = self._sums(st, n + "." + p_bn, "f")
+        lib.bn_stats(bs.z3.data_ptr(), sm.data_ptr(), P_out, b.cout, s)
+        self._bn_finalize(st, n + "." + p_bn, sm, P_out)
+        nxt = E(P_out, b.cout)
+        lib.bn_apply(bs.z3.data_ptr(), self._bnp(st, n + "." + p_bn, 2).data_ptr(), self._bnp(st, n + "." + p_bn, 3).data_ptr(),
+                     cur.data_ptr() if b.skip else None, nxt.data_ptr(), P_out, b.cout, 0, s)
+        bs.Ho, bs.Wo = Ho, Wo
+        st.blocks.append(bs)
+        return nxt, Ho, Wo
+
+    def _run_forward(self, x):
+        a, fl = self.arch, self._flat
+        fl.sync_shadow()
+        s = ops._stream()
+        x = x.contiguous().float()
+        B, _, Hi, Wi = x.shape
+        dev = x.device
+        bf = torch.bfloat16
+        self._step_seed += 1
+        st = SimpleNamespace(B=B, Hi=Hi, Wi=Wi, x=x, blocks=[])
+        st.bnstat = self._buf("bnstat", (4, self._bn_total), torch.float32)
+        st.sums_f = self._buf("sums_f", (2 * self._bn_total,), torch.float32)
+        st.sums_f.zero_()
+        E = lambda *sh, dt=bf: torch.empty(*sh, dtype=dt, device=dev)
+        V, SV = fl.view, fl.sview
+        # ---- stem
+        H, W = Hi // 2, Wi // 2
+        P = B * H * W
+        st.z0 = E(P, a.stem)
+        lib.stem_fwd(x.data_ptr(), V("conv_stem.weight").data_ptr(), st.z0.data_ptr(), self._sums(st, "bn1", "f").data_ptr(),
+                     B, Hi, Wi, a.stem, s)
+        self._bn_finalize(st, "bn1", self._sums(st, "bn1", "f"), P)
+        cur = E(P, a.stem)
+        lib.bn_apply(st.z0.data_ptr(), self._bnp(st, "bn1", 2).data_ptr(), self._bnp(st, "bn1", 3).data_ptr(), None,
+                     cur.data_ptr(), P, a.stem, 1, s)
+        st.x0 = cur
+        # ---- MBConv blocks
+        for b in a.blocks:
+            cur, H, W = self._block_fwd(st, b, cur, H, W)
+        # ---- head conv + BN + SiLU + global average pool (fused into the pooling kernel)
+        P = B * H * W
+        st.x_last, st.Hh, st.Wh = cur, H, W
+        st.zh = E(P, a.head)
+        ops.gemm(cur, SV("conv_head.weight", (a.head, a.last)), st.zh)
+        sm = self._sums(st, "bn2", "f")
+        lib.bn_stats(st.zh.data_ptr(), sm.data_ptr(), P, a.head, s)
+        self._bn_finalize(st, "bn2", sm, P)
+        st.pooled = E(B, a.head, dt=torch.float32)
+        lib.pool_bn_act(st.zh.data_ptr(), self._bnp(st, "bn2", 2).data_ptr(), self._bnp(st, "bn2", 3).data_ptr(), None,
+                        st.pooled.data_ptr(), B, H * W, a.head, 1, 1.0 / (H * W), s)
+        self._nbt += 1
+        return st
+
+    # ------------------------------------------------------------------ backward
+    def _bn_bwd(self, st, name, dy, z, P, C, dz, act, gate=None, dsq=None, hw=1, sums_ready=False):
+        fl = self._flat
+        sums = self._sums(st, name, "b")
+        lib.bn_bwd(dy.data_ptr(), z.data_ptr(), self._bnp(st, name, 0).data_ptr(), self._bnp(st, name, 1).data_ptr(),
+                   self._bnp(st, name, 2).data_ptr(), self._bnp(st, name, 3).data_ptr(),
+                   None if gate is None else gate.data_ptr(), None if dsq is None else dsq.data_ptr(), hw, int(act),
+                   sums.data_ptr(), int(sums_ready), dz.data_ptr(), fl.gview(name + ".weight").data_ptr(),
+                   fl.gview(name + ".bias").data_ptr(), P, C, ops._stream())
+
+    def _block_bwd(self, st, b, bs, dx):
+        """Backward of one MBConv block: dx = dLoss/d(block output) -> returns dLoss/d(block input); parameter
+        gradients are accumulated into the flat gradient buffer."""
+        fl, s = self._flat, ops._stream()
+        B, dev, bf = st.B, dx.device, torch.bfloat16
+        E = lambda *sh, dt=bf: torch.empty(*sh, dtype=dt, device=dev)
+        V, G, SV = fl.view, fl.gview, fl.sview
+        n = b.name
+        e_bn, d_bn, p_bn = _bn_names(b)
+        pw = n + (".conv_pw" if b.type == "ds" else ".conv_pwl")
+        Ho, Wo, Hn, Wn = bs.Ho, bs.Wo, bs.H, bs.W
+        P_out, P_in = B * Ho * Wo, B * Hn * Wn
+        dz3 = E(P_out, b.cout)
+        self._bn_bwd(st, n + "." + p_bn, dx, bs.z3, P_out, b.cout, dz3, act=False)
+        sc2, sh2 = self._bnp(st, n + "." + d_bn, 2), self._bnp(st, n + "." + d_bn, 3)
+        gw3 = G(pw + ".weight").view(b.cout, b.mid)
+        lib.gemm_bf16_xf(2, b.cout, b.mid, P_out, dz3.data_ptr(), b.cout, bs.z2.data_ptr(), b.mid, gw3.data_ptr(), b.mid, 1,
+                         sc2.data_ptr(), sh2.data_ptr(), bs.gate.data_ptr(), Ho * Wo,
+                         ops.pick_split_k(b.cout, b.mid, P_out), 1, s)
+        da2g = E(P_out, b.mid)
+        ops.gemm(dz3, SV(pw + ".weight", (b.cout, b.mid)), da2g, b_kmajor=False)
+        dgate = E(B, b.mid, dt=torch.float32)
+        lib.pool_bn_act(bs.z2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), da2g.data_ptr(), dgate.data_ptr(), B, Ho * Wo, b.mid,
+                        1, 1.0, s)
+        dpe, dr, ds = E(B, b.mid, dt=torch.float32), E(B, b.rd, dt=torch.float32), E(B, b.mid, dt=torch.float32)
+        lib.se_mlp_bwd(dgate.data_ptr(), bs.gate.data_ptr(), bs.hr.data_ptr(), bs.s.data_ptr(),
+                       V(n + ".se.conv_reduce.weight").data_ptr(), V(n + ".se.conv_expand.weight").data_ptr(),
+                       dpe.data_ptr(), dr.data_ptr(), ds.data_ptr(), G(n + ".se.conv_reduce.weight").data_ptr(),
+                       G(n + ".se.conv_reduce.bias").data_ptr(), G(n + ".se.conv_expand.weight").data_ptr(),
+                       G(n + ".se.conv_expand.bias").data_ptr(), B, b.mid, b.rd, s)
+        dz2 = E(P_out, b.mid)
+        self._bn_bwd(st, n + "." + d_bn, da2g, bs.z2, P_out, b.mid, dz2, act=True, gate=bs.gate, dsq=ds, hw=Ho * Wo)
+        del da2g
+        gT = torch.zeros(b.k * b.k, b.mid, dtype=torch.float32, device=dev)
+        lib.dwconv_bwd_weight(dz2.data_ptr(), bs.a1.data_ptr(), gT.data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride, s)
+        lib.dw_grad_from_tap_major(gT.data_ptr(), G(n + ".conv_dw.weight").data_ptr(), b.mid, b.k, s)
+        if b.type == "ir":
+            en = n + "." + e_bn
+            dpre1 = E(P_in, b.mid)
+            lib.dwconv_bwd_data(dz2.data_ptr(), bs.wT.data_ptr(), bs.z1.data_ptr(), self._bnp(st, en, 0).data_ptr(),
+                                self._bnp(st, en, 1).data_ptr(), self._bnp(st, en, 2).data_ptr(), self._bnp(st, en, 3).data_ptr(),
+                                None, dpre1.data_ptr(), self._sums(st, en, "b").data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride, s)
+            dz1 = E(P_in, b.mid)
+            self._bn_bwd(st, en, dpre1, bs.z1, P_in, b.mid, dz1, act=False, sums_ready=True)
+            del dpre1
+            ops.gemm(dz1, bs.x_in, G(n + ".conv_pw.weight").view(b.mid, b.cin), trans_a=True, b_kmajor=False,
+                     split_k=ops.pick_split_k(b.mid, b.cin, P_in), accumulate=True)
+            dx_in = E(P_in, b.cin)
+            ops.gemm(dz1, SV(n + ".conv_pw.weight", (b.mid, b.cin)), dx_in, b_kmajor=False,
+                     epilogue=ops.EPI_ADD if b.skip else ops.EPI_NONE, aux_in=dx if b.skip else None)
+        else:
+            dx_in = E(P_in, b.cin)
+            lib.dwconv_bwd_data(dz2.data_ptr(), bs.wT.data_ptr(), None, None, None, None, None,
+                                dx.data_ptr() if b.skip else None, dx_in.data_ptr(), None, B, Hn, Wn, b.mid, b.k, b.stride, s)
+        if self.grad_ready_hook:
+            first = n + (".conv_pw.weight" if b.type == "ir" else ".conv_dw.weight")
+            self.grad_ready_hook(fl, *fl.span(first, n + "." + p_bn + ".bias"))
+        return dx_in
+
+    def _run_backward(self, st, dpooled):
+        a, fl = self.arch, self._flat
+        self._bind_grads()
+        s = ops._stream()
+        B = st.B
+        dev = dpooled.device
+        bf = torch.bfloat16
+        E = lambda *sh, dt=bf: torch.empty(*sh, dtype=dt, device=dev)
+        V, G, SV = fl.view, fl.gview, fl.sview
+        st.sums_b = self._buf("sums_b", (2 * self._bn_total,), torch.float32)
+        st.sums_b.zero_()
+        dpooled = dpooled.contiguous().float()
+        # ---- head
+        H, W = st.Hh, st.Wh
+        P = B * H * W
+        dyh = E(P, a.head)
+        lib.broadcast_pool_grad(dpooled.data_ptr(), dyh.data_ptr(), B, H * W, a.head, s)
+        dzh = E(P, a.head)
+        self._bn_bwd(st, "bn2", dyh, st.zh, P, a.head, dzh, act=True)
+        ops.gemm(dzh, st.x_last, G("conv_head.weight").view(a.head, a.last), trans_a=True, b_kmajor=False,
+                 split_k=ops.pick_split_k(a.head, a.last, P), accumulate=True)
+        dx = E(P, a.last)
+        ops.gemm(dzh, SV("conv_head.weight", (a.head, a.last)), dx, b_kmajor=False)
+        del dyh, dzh
+        # ---- blocks, last to first
+        for b, bs in zip(reversed(a.blocks), reversed(st.blocks)):
+            dx = self._block_bwd(st, b, bs, dx)
+        # ---- stem
+        P0 = B * (st.Hi // 2) * (st.Wi // 2)
+        dz0 = E(P0, a.stem)
+        self._bn_bwd(st, "bn1", dx, st.z0, P0, a.stem, dz0, act=True)
+        lib.stem_wgrad(dz0.data_ptr(), st.x.data_ptr(), G("conv_stem.weight").data_ptr(), B, st.Hi, st.Wi, a.stem, s)
+        if self.grad_ready_hook:
+            self.grad_ready_hook(fl, *fl.span("conv_stem.weight", "bn1.bias"))
+            self.grad_ready_hook(fl, *fl.span("conv_head.weight", "bn2.bias"))
+
+
+class _EffFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, x):
+        st = model._run_forward(x)
+        ctx.model, ctx.st = model, st
+        return st.pooled.clone()
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        ctx.model._run_backward(ctx.st, dpooled)
+        ctx.st = None
+        return None, None, None

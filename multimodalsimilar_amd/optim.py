@@ -1,0 +1,75 @@
+"""Fused AdamW over flat parameter buffers + the linear schedule the reference's train script uses.
+
+``FusedAdamW`` is a ``torch.optim.Optimizer`` (so ``transformers.get_scheduler`` / ``LambdaLR`` drive its
+``param_groups[...]['lr']`` exactly as they drive torch's AdamW in multimodal_classifier_train.py:152-164), but
+``step()`` is ONE HIP launch per flat buffer (mmsim_adamw_step) that also refreshes the bf16 shadow weights.
+Semantics = torch.optim.AdamW defaults (betas 0.9/0.999, eps 1e-8, weight_decay 0.01).
+Parameters outside any flat buffer (the reference's dead layers, which never receive gradients) are skipped, as
+torch skips parameters whose ``.grad`` is None.
+"""
+import torch
+
+from . import ops
+
+
+def collect_flat_buffers(modules):
+    if isinstance(modules, torch.nn.Module):
+        modules = [modules]
+    seen, out = set(), []
+    for root in modules:
+        for m in root.modules():
+            fb = getattr(m, "flat_buffers", None)
+            if fb is None:
+                continue
+            for f in fb():
+                if id(f) not in seen:
+                    seen.add(id(f))
+                    out.append(f)
+    return out
+
+
+def linear_schedule_lr(lr0, t, warmup, total):
+    """transformers.get_scheduler('linear') lambda (warmup may be a float, as in the reference: 0.15*T)."""
+    if t < warmup:
+        return lr0 * float(t) / float(max(1, warmup))
+    return lr0 * max(0.0, float(total - t) / float(max(1, total - warmup)))
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, modules, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_scale=1.0):
+        self.flats = collect_flat_buffers(modules)
+        if not self.flats:
+            raise ValueError("FusedAdamW: no flat parameter buffers found under the given modules")
+        if isinstance(modules, torch.nn.Module):
+            modules = [modules]
+        params, seen = [], set()
+        for m in modules:
+            for p in m.parameters():
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    params.append(p)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.grad_scale = grad_scale
+        self._t = 0
+        self._mv = {}
+
+    def zero_grad(self, set_to_none=False):
+        for f in self.flats:
+            f.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self._t += 1
+        for f in self.flats:
+            if f.grad is None:
+                continue          # never produced a gradient: skipped like torch skips grad-is-None params
+            f.ensure_device_state()
+            mv = self._mv.get(id(f))
+            if mv is None or mv[0].device != f.master.device:
+                mv = (torch.zeros_like(f.master), torch.zeros_like(f.master))
+                self._mv[id(f)] = mv
+            ops.adamw_step(f.master, f.grad, mv[0], mv[1], f.shadow, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                           g["weight_decay"], self._t, self.grad_scale)
+            f._shadow_version = f.master._version
+        return None

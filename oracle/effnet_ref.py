@@ -124,46 +124,61 @@ def _se(x, sd, n):
     return x * torch.sigmoid(s)
 
 
-def backbone_forward(sd, model_name, x, training=True, stats=None, taps=None):
-    """x [B,3,H,W] -> feature map [B,head,H/32,W/32].  sd keys carry the 'backbone.' prefix."""
+def _q(t, on):
+    """bf16 storage emulation (round to bf16, compute in fp32); gradient passes straight through the casts."""
+    return t.bfloat16().float() if on else t
+
+
+def mbconv_forward(sd, n, b, x, training=True, stats=None, e=False):
+    """One DS / IR block; n = state-dict prefix of the block, b = its arch() entry."""
+    sc = x
+    if b["type"] == "ds":
+        x = _q(F.conv2d(x, sd[n + ".conv_dw.weight"], None, stride=b["stride"], padding=b["k"] // 2, groups=b["mid"]), e)
+        x = F.silu(_bn(x, sd, n + ".bn1", training, stats))
+        x = _q(_se(x, sd, n), e)
+        x = _q(F.conv2d(x, _q(sd[n + ".conv_pw.weight"], e)), e)
+        x = _bn(x, sd, n + ".bn2", training, stats)
+    else:
+        x = _q(F.conv2d(x, _q(sd[n + ".conv_pw.weight"], e)), e)
+        x = _q(F.silu(_bn(x, sd, n + ".bn1", training, stats)), e)
+        x = _q(F.conv2d(x, sd[n + ".conv_dw.weight"], None, stride=b["stride"], padding=b["k"] // 2, groups=b["mid"]), e)
+        x = F.silu(_bn(x, sd, n + ".bn2", training, stats))
+        x = _q(_se(x, sd, n), e)
+        x = _q(F.conv2d(x, _q(sd[n + ".conv_pwl.weight"], e)), e)
+        x = _bn(x, sd, n + ".bn3", training, stats)
+    if b["skip"]:
+        x = x + sc
+    return _q(x, e)
+
+
+def backbone_forward(sd, model_name, x, training=True, stats=None, taps=None, emulate_bf16=False):
+    """x [B,3,H,W] -> feature map [B,head,H/32,W/32].  sd keys carry the 'backbone.' prefix.
+
+    emulate_bf16=True rounds to bf16 exactly where the MI355X path stores bf16 (conv outputs before BatchNorm,
+    activated tensors that are materialised, block outputs, 1x1-conv weights) and keeps fp32 everywhere else.
+    It is the same algorithm; it separates "bf16 storage" error from implementation error in the parity tests."""
     a = arch(model_name)
     p = "backbone."
-    x = F.conv2d(x, sd[p + "conv_stem.weight"], None, stride=2, padding=1)
-    x = F.silu(_bn(x, sd, p + "bn1", training, stats))
+    e = emulate_bf16
+    x = _q(F.conv2d(x, sd[p + "conv_stem.weight"], None, stride=2, padding=1), e)
+    x = _q(F.silu(_bn(x, sd, p + "bn1", training, stats)), e)
     if taps is not None:
         taps["stem"] = x
     for b in a["blocks"]:
-        n = p + b["name"]
-        sc = x
-        if b["type"] == "ds":
-            x = F.conv2d(x, sd[n + ".conv_dw.weight"], None, stride=b["stride"], padding=b["k"] // 2, groups=b["mid"])
-            x = F.silu(_bn(x, sd, n + ".bn1", training, stats))
-            x = _se(x, sd, n)
-            x = F.conv2d(x, sd[n + ".conv_pw.weight"])
-            x = _bn(x, sd, n + ".bn2", training, stats)
-        else:
-            x = F.conv2d(x, sd[n + ".conv_pw.weight"])
-            x = F.silu(_bn(x, sd, n + ".bn1", training, stats))
-            x = F.conv2d(x, sd[n + ".conv_dw.weight"], None, stride=b["stride"], padding=b["k"] // 2, groups=b["mid"])
-            x = F.silu(_bn(x, sd, n + ".bn2", training, stats))
-            x = _se(x, sd, n)
-            x = F.conv2d(x, sd[n + ".conv_pwl.weight"])
-            x = _bn(x, sd, n + ".bn3", training, stats)
-        if b["skip"]:
-            x = x + sc
+        x = mbconv_forward(sd, p + b["name"], b, x, training, stats, e)
         if taps is not None:
             taps[b["name"]] = x
-    x = F.conv2d(x, sd[p + "conv_head.weight"])
+    x = _q(F.conv2d(x, _q(sd[p + "conv_head.weight"], e)), e)
     x = F.silu(_bn(x, sd, p + "bn2", training, stats))
     return x
 
 
-def cv_predict_emb(sd, model_name, x, use_fc=True, training=True, stats=None, taps=None):
+def cv_predict_emb(sd, model_name, x, use_fc=True, training=True, stats=None, taps=None, emulate_bf16=False):
     """cv_classifier.py:47-55 (dropout = identity)."""
-    f = backbone_forward(sd, model_name, x, training, stats, taps)
+    f = backbone_forward(sd, model_name, x, training, stats, taps, emulate_bf16)
     e = f.mean((2, 3))                                    # AdaptiveAvgPool2d(1).view(B,-1)   :50
     if use_fc:
-        e = F.linear(e, sd["fc.weight"], sd["fc.bias"])   # :53
+        e = F.linear(_q(e, emulate_bf16), _q(sd["fc.weight"], emulate_bf16), sd["fc.bias"])   # :53
         e = _bn(e, sd, "bn", training, stats)             # :54
     return e
 
