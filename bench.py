@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: the data-parallel two-tower (RoBERTa-wwm-ext-large + EfficientNet-B4) + ArcFace
+training step, BASELINE.json's metric, on synthetic inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = forward (both towers, normalise+concat, fused ArcFace margin + cross-entropy) + backward + gradient
+all-reduce (N > 1) + both fused AdamW updates + LR schedules: nothing is skipped or cached inside the timed region.
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline     - the dominant kernel (the bf16 MFMA GEMM gemm_bf16_kernel<false,true,0>, Y = X W^T): algorithmic
+                 FLOPs (2 M N K per launch) / its mean launch duration measured with HIP events on the launch stream
+                 over the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak (MI355X_MICROARCH.md);
+  cpu_baseline - the oracle's CPU restatement of the same step (oracle/step_ref.py, kind "port") on the host cores,
+                 on a bounded sample (same model, B_cpu pairs per step).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_flops_per_pair(cfg):
+    """fwd+bwd = 3 x fwd, 1 MAC = 2 FLOP; elementwise / softmax / LN not counted."""
+    f = 0.0
+    if cfg["kind"] in ("nlp", "multimodal"):
+        L, H, S = (24, 1024, cfg["seq_len"]) if cfg["text"] == "large" else ((12, 768, cfg["seq_len"]) if cfg["text"] == "base" else (2, 128, cfg["seq_len"]))
+        f += 3 * L * (24 * S * H * H + 4 * S * S * H)
+        D = H
+    if cfg["kind"] in ("cv", "multimodal"):
+        from oracle import effnet_ref
+        macs, _ = effnet_ref.count_macs_params(cfg["image"], cfg["res"])
+        f += 3 * 2 * macs
+        D = (cfg.get("fc_dim", 0) if cfg.get("use_fc") else {"efficientnet_b0": 1280, "efficientnet_b4": 1792}[cfg["image"]]) + \
+            (D if cfg["kind"] == "multimodal" else 0)
+    f += 6 * D * cfg["classes"]
+    return f
+
+
+class GemmTimer:
+    """HIP events around every launch of the forward-layout GEMM (trans_a=0, b_kmajor=1) on the launch stream."""
+
+    def __init__(self, ops):
+        self.ops, self.orig, self.rec, self.on = ops, ops.gemm, [], False
+
+    def install(self):
+        def timed(a, b, c, *, trans_a=False, b_kmajor=True, **kw):
+            if not self.on or trans_a or not b_kmajor:
+                return self.orig(a, b, c, trans_a=trans_a, b_kmajor=b_kmajor, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self.orig(a, b, c, trans_a=trans_a, b_kmajor=b_kmajor, **kw)
+            e1.record()
+            self.rec.append((e0, e1, 2.0 * c.shape[0] * c.shape[1] * a.shape[1]))
+            return r
+        self.ops.gemm = timed
+
+    def summary(self):
+        if not self.rec:
+            return None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec)
+        fl = sum(f for _, _, f in self.rec)
+        return dict(launches=len(self.rec), avg_us=1e3 * ms / len(self.rec), tflops=fl / (ms * 1e-3) / 1e12)
+
+
+def cpu_baseline(cfg, b_cpu, steps):
+    """Oracle (CPU restatement) of the same step on the host cores; bounded sample: b_cpu pairs per step."""
+    from oracle import bert_ref, effnet_ref, step_ref
+    torch.manual_seed(0)
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    kind = cfg["kind"]
+    ts = ti = None
+    shape = None
+    D = 0
+    if kind in ("nlp", "multimodal"):
+        big = cfg["text"] == "large"
+        shape = bert_ref.BertShape(21128, 1024 if big else 768, 24 if big else 12, 16 if big else 12, 4096 if big else 3072)
+        ts = bert_ref.init_state(shape, seed=0)
+        D += shape.hidden_size
+    if kind in ("cv", "multimodal"):
+        ti = effnet_ref.init_state(cfg["image"], fc_dim=cfg.get("fc_dim") if cfg.get("use_fc") else None, seed=0)
+        D += cfg["fc_dim"] if cfg.get("use_fc") else effnet_ref.arch(cfg["image"])["head"]
+    head = torch.empty(cfg["classes"], D)
+    torch.nn.init.xavier_uniform_(head)
+    orc = step_ref.TwoTowerOracle(shape, ts, cfg.get("image"), ti, head, num_steps=10 ** 6, use_fc=bool(cfg.get("use_fc")),
+                                  margin={"multimodal": 0.5, "nlp": 0.4, "cv": 0.2}[kind])
+    from multimodalsimilar_amd.train import synthetic_batch
+    batch = synthetic_batch(cfg, "cpu", seed=4321, batch=b_cpu)
+    orc.step(batch)                         # first call pays allocator / thread-pool start-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        orc.step(batch)
+    dt = (time.perf_counter() - t0) / steps
+    model = ""
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return dict(value=b_cpu / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{steps} timed steps of the identical step at B_cpu={b_cpu} pairs (fp32, torch CPU ops via oracle/step_ref.py), "
+                       f"{dt:.2f} s/step; host: {ncores} logical cores, {model}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg4")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (reported; invalid as the headline)")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--literal-loss", action="store_true", help="materialised logits + nn.CrossEntropyLoss instead of the fused head")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from multimodalsimilar_amd import build, ops
+    if rank == 0:
+        build.build(verbose=False)
+    if world > 1:
+        dist.barrier()
+    from multimodalsimilar_amd import train
+
+    cfg = dict(train.CONFIGS[args.config])
+    if args.batch:
+        cfg["batch"] = args.batch
+    model = train.build_model(cfg, device, seed=0, dropout=not args.no_dropout)
+    step = train.TrainStep(model, cfg["kind"], num_training_steps=10 ** 6, fused_loss=not args.literal_loss)
+    batch = train.synthetic_batch(cfg, device, seed=1234 + rank)
+    timer = GemmTimer(ops)
+    timer.install()
+
+    for _ in range(args.warmup):
+        loss, _ = step.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, pred = step.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.on = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    model.classifier.check_labels()
+    lossv = float(loss.item())
+
+    if rank == 0:
+        pairs = world * cfg["batch"] * args.steps
+        ms = 1e3 * elapsed / args.steps
+        fpp = algorithmic_flops_per_pair(cfg)
+        g = timer.summary()
+        out = {
+            "metric": "image-text pairs/sec/step (two-tower+ArcFace, bs=256)", "value": pairs / elapsed, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.config}: " + {"multimodal": "roberta-wwm-ext-large + efficientnet_b4 two-tower + ArcFace",
+                                                        "nlp": "text tower + ArcFace", "cv": "image tower + ArcFace"}[cfg["kind"]],
+                       "per_gpu_batch": cfg["batch"], "global_batch": world * cfg["batch"], "seq_len": cfg.get("seq_len"),
+                       "image": cfg.get("res"), "classes": cfg["classes"], "parallelism": f"dp{world}",
+                       "dropout": not args.no_dropout, "loss_path": "literal" if args.literal_loss else "fused",
+                       "algorithmic_gflop_per_pair": fpp / 1e9,
+                       "step_mfma_frac": (fpp * cfg["batch"] / (ms * 1e-3) / 1e12) / MFMA_BF16_PEAK_TFLOPS,
+                       "final_loss": lossv},
+            "roofline": None if g is None else {
+                "bound": "mfma", "kernel": "gemm_bf16_kernel<false,true,0> (Y = X W^T, bf16 MFMA 16x16x32, fp32 accumulate)",
+                "achieved": g["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / MFMA_BF16_PEAK_TFLOPS,
+                "traffic": None, "launches": g["launches"], "avg_launch_us": g["avg_us"]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, args.cpu_steps)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,9 @@ class _Lib:
     def load(self):
         if self._dll is not None:
             return self
+        # torch bundles its own libamdhip64.so.7; it must be the HIP runtime of the process (loaded first), otherwise
+        # two runtimes coexist and launches fail with "no ROCm-capable device is detected"
+        import torch  # noqa: F401
         if not os.path.exists(LIBPATH):
             raise MmsimError(
                 f"{LIBPATH} not found: the HIP library has not been built "

@@ -36,13 +36,14 @@ def linear_schedule_lr(lr0, t, warmup, total):
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, modules, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_scale=1.0):
-        self.flats = collect_flat_buffers(modules)
+    def __init__(self, modules, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_scale=1.0, exclude=()):
+        skip = {id(f) for f in collect_flat_buffers(list(exclude))} if exclude else set()
+        self.flats = [f for f in collect_flat_buffers(modules) if id(f) not in skip]
         if not self.flats:
             raise ValueError("FusedAdamW: no flat parameter buffers found under the given modules")
         if isinstance(modules, torch.nn.Module):
             modules = [modules]
-        params, seen = [], set()
+        params, seen = [], {id(p) for e in exclude for p in e.parameters()}
         for m in modules:
             for p in m.parameters():
                 if id(p) not in seen:

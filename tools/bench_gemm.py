@@ -1,0 +1,39 @@
+"""GEMM micro-benchmark on the text-tower shapes (GPU box): correctness vs torch + TFLOP/s per layout."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimodalsimilar_amd import ops
+dev = "cuda"
+M = int(os.environ.get("GM", 32768))
+shapes = [("qkv", 3072, 1024), ("o", 1024, 1024), ("ffn1", 4096, 1024), ("ffn2", 1024, 4096)]
+def bench(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+tot_t = tot_f = 0
+for name, N, K in shapes:
+    x = (torch.randn(M, K, device=dev)).bfloat16(); w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    dy = (torch.randn(M, N, device=dev)).bfloat16()
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    dx = torch.empty(M, K, dtype=torch.bfloat16, device=dev)
+    dw = torch.zeros(N, K, dtype=torch.float32, device=dev)
+    bias = torch.zeros(N, device=dev)
+    fl = 2.0 * M * N * K
+    ops.gemm(x, w, y, bias=bias); ref = x.float() @ w.float().t()
+    e_nt = ((y.float() - ref).abs().max() / ref.abs().max()).item()
+    ops.gemm(dy, w, dx, b_kmajor=False); ref = dy.float() @ w.float()
+    e_nn = ((dx.float() - ref).abs().max() / ref.abs().max()).item()
+    sk = ops.pick_split_k(N, K, M)
+    ops.gemm(dy, x, dw, trans_a=True, b_kmajor=False, split_k=sk, accumulate=True); ref = dy.float().t() @ x.float()
+    e_tn = ((dw - ref).abs().max() / ref.abs().max()).item()
+    t_nt = bench(lambda: ops.gemm(x, w, y, bias=bias))
+    t_nn = bench(lambda: ops.gemm(dy, w, dx, b_kmajor=False))
+    t_tn = bench(lambda: ops.gemm(dy, x, dw, trans_a=True, b_kmajor=False, split_k=sk, accumulate=True))
+    t_ref = bench(lambda: torch.matmul(x, w.t()))
+    print(f"{name:5s} M={M} N={N} K={K}: NT {fl/t_nt/1e9:7.1f} TF ({e_nt:.1e})  NN {fl/t_nn/1e9:7.1f} TF ({e_nn:.1e})  "
+          f"TN(sk={sk}) {fl/t_tn/1e9:7.1f} TF ({e_tn:.1e})   [torch/hipBLASLt NT {fl/t_ref/1e9:7.1f} TF]", flush=True)
+    tot_t += t_nt + t_nn + t_tn; tot_f += 3 * fl
+print(f"layer total: {tot_t:.3f} ms per layer fwd+bwd GEMMs -> {tot_f/tot_t/1e9:.1f} TF average; x24 = {24*tot_t:.1f} ms")
