@@ -14,7 +14,8 @@
 // Global->LDS staging is register-staged and split (issue loads for tile t+1, compute tile t, then write):
 // one barrier per K-step on double-buffered LDS.  Blocks are remapped so that the tiles an XCD works on
 // are neighbours (shared A panel in that XCD's L2).
-#include "common.h"
+#include "gemm_common.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -22,17 +23,6 @@
 #define KM_PITCH 160                       // bytes per k-major row (128 B data + 32 B pad)
 #define OP_STAGE_BYTES (BM * KM_PITCH)     // 20480 >= 64*256 (transposed-staged operand)
 #define STAGE_BYTES (2 * OP_STAGE_BYTES)
-
-struct GemmParams {
-  const bf16* A; const bf16* B; void* C; const float* bias; const bf16* aux_in; bf16* aux_out;
-  int M, N, K, lda, ldb, ldc, ld_aux;
-  int c_f32, epi, atomic, accum, k_per_split, tiles_m, tiles_n;
-  float alpha;
-  // optional operand transform (1x1 conv after BN + SiLU + squeeze-excite): x -> silu(scale[c] x + shift[c]) * gate[b, c]
-  const float* xf_scale; const float* xf_shift; const float* xf_gate; int xf_hw, xf_C;
-};
-
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_MUL_GELU_GRAD = 2, EPI_ADD = 3, EPI_TANH = 4 };
 
 __device__ __forceinline__ int tr_key(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
@@ -130,13 +120,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   const int wm = wave >> 1, wn = wave & 1;
 
   // XCD-aware bijective remap of the 1-D grid onto tiles
-  const int nwg = p.tiles_m * p.tiles_n;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int nwg = ntiles * p.splits;
   const int bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  const int tm = wg / p.tiles_n, tn = wg % p.tiles_n;
+  const int split = wg / ntiles, tile = wg - split * ntiles;
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = blockIdx.y * p.k_per_split;
+  const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
@@ -186,80 +178,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  // epilogue: lane owns row m = .. + (lane&15), columns n = .. + (lane>>4)*4 + {0,1,2,3}
-  const bool add_bias = (p.bias != nullptr) && (blockIdx.y == 0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-      if (n >= p.N) continue;
-      float v[4] = {acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
-      const bool full = (n + 3 < p.N);
-      if (add_bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (n + e < p.N) v[e] += p.bias[n + e];
-      }
-      if (p.epi == EPI_GELU) {
-        bf16* ao = p.aux_out + (size_t)m * p.ld_aux + n;
-        if (full) {
-          bf4 pre = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-          *reinterpret_cast<bf4*>(ao) = pre;
-        } else {
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) ao[e] = f2bf(v[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_f(bf2f(f2bf(v[e])));   // gelu of the stored (rounded) pre-activation
-      } else if (p.epi == EPI_MUL_GELU_GRAD) {
-        const bf16* ai = p.aux_in + (size_t)m * p.ld_aux + n;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (n + e < p.N) v[e] *= gelu_grad_f(bf2f(ai[e]));
-      } else if (p.epi == EPI_ADD) {
-        const bf16* ai = p.aux_in + (size_t)m * p.ld_aux + n;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (n + e < p.N) v[e] += bf2f(ai[e]);
-      } else if (p.epi == EPI_TANH) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
-      }
-      if (p.c_f32) {
-        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-        if (p.atomic) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) atomicAdd(c + e, v[e]);
-        } else if (full) {
-          float4 o = make_float4(v[0], v[1], v[2], v[3]);
-          if (p.accum) {
-            const float4 old = *reinterpret_cast<const float4*>(c);
-            o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-          }
-          *reinterpret_cast<float4*>(c) = o;
-        } else {
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) c[e] = p.accum ? c[e] + v[e] : v[e];
-        }
-      } else {
-        bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
-        if (full) {
-          bf4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-          *reinterpret_cast<bf4*>(c) = o;
-        } else {
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) c[e] = f2bf(v[e]);
-        }
-      }
-    }
-  }
+  gemm_epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, lane, split == 0);
 }
 
 // C-ABI -- see include/mmsim_hip.h for the contract.
+bool gemm_fast_eligible(const GemmParams& p, int splits);
+void gemm_fast_launch(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s);
+
+static bool force_generic() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MMSIM_GEMM_GENERIC"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
 static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B,
                      int ldb, void* C, int ldc, int c_is_f32, const float* bias, int epilogue,
                      const void* aux_in, void* aux_out, int ld_aux, float alpha, int split_k,
@@ -293,9 +224,14 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   kps = ((kps + BK - 1) / BK) * BK;
   p.k_per_split = kps;
   const int splits = (K + kps - 1) / kps;
-  dim3 grid(p.tiles_m * p.tiles_n, splits), block(256);
+  p.splits = splits;
+  dim3 grid(p.tiles_m * p.tiles_n * splits), block(256);
   const size_t lds = 2 * STAGE_BYTES;
   hipStream_t s = (hipStream_t)stream;
+  if (xf_operand == 0 && !force_generic() && gemm_fast_eligible(p, splits)) {
+    gemm_fast_launch(p, trans_a, b_kmajor, splits, s);
+    return mmsim_check_launch("gemm_bf16_fast");
+  }
   static bool attr_done = false;
   if (!attr_done) {   // 80 KiB of dynamic LDS per block needs the opt-in on every instantiation
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

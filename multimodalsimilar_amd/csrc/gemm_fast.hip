@@ -1,0 +1,406 @@
+// Fast path of the bf16 MFMA GEMM for tile-aligned shapes (the text tower): 256x128x64 tiles, 512 threads = 8 waves
+// (4 along M x 2 along N, 64x64 each), operands brought HBM -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no
+// VGPR staging), a 3-slot LDS ring with TWO K-tiles in flight behind a counted s_waitcnt vmcnt and ONE raw s_barrier
+// per K-step (cdna_hip_programming.md section 5, "Pipelining across barriers" / "3-buf span").
+//
+// LDS-DMA writes lane-linearly (wave-uniform base + lane*16), so the bank-conflict swizzle is applied to the SOURCE
+// address and undone on the read (guide rule 21):
+//   k-major operand   [rows][64 k]  (128-B rows): 16-B chunk c of row r is stored at chunk c ^ ((r >> 1) & 7)
+//                                                  -> ds_read_b128 fragments are conflict-free;
+//   transposed operand [64 k][cols] (256/512-B rows): 32-B column block cb of k-row k at block cb ^ key(k)
+//                                                  -> ds_read_b64_tr_b16 fragments are conflict-free.
+// Per step t:  wait(tile t landed: vmcnt(6) leaves tile t+1 in flight) -> s_barrier -> issue tile t+2 into the
+// slot read in step t-1 (every wave has passed the barrier, so nobody still reads it) -> 32 MFMAs per wave on tile t.
+#include "gemm_common.h"
+#include <stdlib.h>
+
+#define FBM 256
+#define FBN 128
+#define FBK 64
+#define FA_STAGE (FBM * 128)                 // 32 KiB either layout
+#define FB_STAGE (FBN * 128)                 // 16 KiB either layout
+#define F_STAGE (FA_STAGE + FB_STAGE)        // 48 KiB; x3 slots = 144 KiB of the CU's 160 KiB
+
+typedef s4 __attribute__((address_space(3))) * lds_s4_ptr;
+typedef void __attribute__((address_space(3))) * lds_void_ptr;
+typedef const void __attribute__((address_space(1))) * glb_void_ptr;
+
+__device__ __forceinline__ int ftr_key(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+// Issue the LDS-DMA of one operand tile.  NI = wave-instructions per wave (ROWS*128 bytes / 8 waves / 1 KiB).
+// TRANS = false: tile [ROWS][64 k] from X[(r0+row)*ld + k0 + ...];  TRANS = true: tile [64 k][ROWS] from X[(k0+k)*ld + r0 + ...]
+template <bool TRANS, int ROWS>
+__device__ __forceinline__ void dma_tile(const bf16* __restrict__ X, int ld, int r0, int k0, char* lds, int wave, int lane) {
+  constexpr int NI = ROWS * 128 / (8 * 1024);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int blk = wave * NI + i;                       // 1-KiB block of the tile image
+    const bf16* src;
+    if (!TRANS) {
+      const int row = blk * 8 + (lane >> 3), pos = lane & 7;
+      const int c = pos ^ ((row >> 1) & 7);
+      src = X + (size_t)(r0 + row) * ld + k0 + c * 8;
+    } else {
+      constexpr int CPR = ROWS / 8;                      // 16-B chunks per k-row (16 or 32)
+      constexpr int RPB = 64 / CPR;                      // k-rows per 1-KiB block (4 or 2)
+      const int k = blk * RPB + lane / CPR, pc = lane % CPR;
+      const int c = (((pc >> 1) ^ ftr_key(k)) << 1) | (pc & 1);
+      src = X + (size_t)(k0 + k) * ld + r0 + c * 8;
+    }
+    __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(lds + blk * 1024), 16, 0, 0);
+  }
+}
+
+template <bool TRANS, int ROWS>
+__device__ __forceinline__ bf8 ffrag(const char* lds, int rbase, int ks, int lane) {
+  if (!TRANS) {
+    const int row = rbase + (lane & 15), kc = ks * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf8*>(lds + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+  } else {
+    constexpr int ROWB = ROWS * 2;
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int k = ks * 32 + 8 * g + q;
+    const int cb = rbase >> 4;
+    const int off = k * ROWB + ((cb ^ ftr_key(k)) << 5) + p * 8;
+    s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(lds + off));
+    s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(lds + off + 4 * ROWB));
+    s8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(bf8, r);
+  }
+}
+
+// Epilogue for full tiles, staged through LDS so that every global access is row-contiguous: the wave's 64x64
+// fp32 tile is written to its private LDS region (the operand ring is free by then) and read back one row segment
+// per 16 lanes: 128-B bf16 / 256-B fp32 stores and aux loads (whole cache lines), and for split-K one 256-B
+// contiguous atomic wave-instruction per row (the shape float atomics run at full rate in, MI355X_MICROARCH.md).
+// CMODE: 0 bf16 store, 1 f32 store, 2 f32 +=, 3 f32 atomic add.
+#define EP_PITCH 68     // floats per staged row (64 + 4 pad: 16-byte aligned rows)
+template <int EPI, int CMODE>
+__device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][4], int row0, int col0, int lane, bool first_split,
+                                              float* tile) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f4*>(tile + (i * 16 + (lane & 15)) * EP_PITCH + j * 16 + (lane >> 4) * 4) = acc[i][j];
+  if (CMODE == 3) {
+#pragma unroll 8
+    for (int r = 0; r < 64; ++r)
+      atomicAdd(reinterpret_cast<float*>(p.C) + (size_t)(row0 + r) * p.ldc + col0 + lane, tile[r * EP_PITCH + lane] * p.alpha);
+    return;
+  }
+  const int c4 = (lane & 15) * 4, n = col0 + c4;
+  const bool add_bias = (p.bias != nullptr) && first_split;
+  const float4 bias = add_bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int r = it * 4 + (lane >> 4);
+    const size_t m = (size_t)(row0 + r);
+    const f4 a = *reinterpret_cast<const f4*>(tile + r * EP_PITCH + c4);
+    float v[4] = {a[0] * p.alpha + bias.x, a[1] * p.alpha + bias.y, a[2] * p.alpha + bias.z, a[3] * p.alpha + bias.w};
+    if (EPI == EPI_GELU) {
+      bf4 pre = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+      *reinterpret_cast<bf4*>(p.aux_out + m * p.ld_aux + n) = pre;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_f(bf2f(pre[e]));
+    } else if (EPI == EPI_MUL_GELU_GRAD) {
+      const bf4 x = *reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(bf2f(x[e]));
+    } else if (EPI == EPI_ADD) {
+      const bf4 x = *reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += bf2f(x[e]);
+    } else if (EPI == EPI_TANH) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+    }
+    if (CMODE == 0) {
+      bf4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+      *reinterpret_cast<bf4*>(reinterpret_cast<bf16*>(p.C) + m * p.ldc + n) = o;
+    } else {
+      float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
+      if (CMODE == 1) {
+        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        const float4 old = *reinterpret_cast<const float4*>(c);
+        *reinterpret_cast<float4*>(c) = make_float4(v[0] + old.x, v[1] + old.y, v[2] + old.z, v[3] + old.w);
+      }
+    }
+  }
+}
+
+template <int CMODE>
+__device__ __forceinline__ void fast_epilogue_epi(const GemmParams& p, f4 (&acc)[4][4], int row0, int col0, int lane, bool first_split,
+                                                  float* tile) {
+  switch (p.epi) {
+    case EPI_GELU: fast_epilogue<EPI_GELU, CMODE>(p, acc, row0, col0, lane, first_split, tile); break;
+    case EPI_MUL_GELU_GRAD: fast_epilogue<EPI_MUL_GELU_GRAD, CMODE>(p, acc, row0, col0, lane, first_split, tile); break;
+    case EPI_ADD: fast_epilogue<EPI_ADD, CMODE>(p, acc, row0, col0, lane, first_split, tile); break;
+    case EPI_TANH: fast_epilogue<EPI_TANH, CMODE>(p, acc, row0, col0, lane, first_split, tile); break;
+    default: fast_epilogue<EPI_NONE, CMODE>(p, acc, row0, col0, lane, first_split, tile); break;
+  }
+}
+
+template <bool TA, bool TB_KMAJOR>
+__global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // 1-D grid over (split, tile); blocks that share operand panels (same split, neighbouring tiles) are made
+  // consecutive and each XCD gets one contiguous chunk of them, so its private L2 serves the re-reads
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int nwg = ntiles * p.splits;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int split = wg / ntiles, tile = wg - split * ntiles;
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const int m0 = tm * FBM, n0 = tn * FBN;
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg) / FBK;
+
+  f4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  // prologue: tiles 0 and 1 in flight
+  dma_tile<TA, FBM>(p.A, p.lda, m0, kbeg, smem, wave, lane);
+  dma_tile<!TB_KMAJOR, FBN>(p.B, p.ldb, n0, kbeg, smem + FA_STAGE, wave, lane);
+  if (nk > 1) {
+    dma_tile<TA, FBM>(p.A, p.lda, m0, kbeg + FBK, smem + F_STAGE, wave, lane);
+    dma_tile<!TB_KMAJOR, FBN>(p.B, p.ldb, n0, kbeg + FBK, smem + F_STAGE + FA_STAGE, wave, lane);
+  }
+  int slot = 0;
+  for (int t = 0; t < nk; ++t) {
+    // each wave issues 6 LDS-DMA instructions per tile: vmcnt(6) = "tile t landed, tile t+1 may still fly"
+    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 2 < nk) {
+      int ns = slot + 2; if (ns >= 3) ns -= 3;
+      dma_tile<TA, FBM>(p.A, p.lda, m0, kbeg + (t + 2) * FBK, smem + ns * F_STAGE, wave, lane);
+      dma_tile<!TB_KMAJOR, FBN>(p.B, p.ldb, n0, kbeg + (t + 2) * FBK, smem + ns * F_STAGE + FA_STAGE, wave, lane);
+    }
+    const char* la = smem + slot * F_STAGE;
+    const char* lb = la + FA_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = ffrag<TA, FBM>(la, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = ffrag<!TB_KMAJOR, FBN>(lb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    slot = slot + 1; if (slot >= 3) slot = 0;
+  }
+  const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;
+  const bool fs = split == 0;
+  __syncthreads();                                  // every wave is done reading the operand ring: reuse it for staging
+  float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
+  if (!p.c_f32) fast_epilogue_epi<0>(p, acc, row0, col0, lane, fs, stg);      // bf16 outputs carry the fused epilogues
+  else if (p.atomic) fast_epilogue<EPI_NONE, 3>(p, acc, row0, col0, lane, fs, stg);
+  else if (p.accum) fast_epilogue<EPI_NONE, 2>(p, acc, row0, col0, lane, fs, stg);
+  else if (p.epi == EPI_TANH) fast_epilogue<EPI_TANH, 1>(p, acc, row0, col0, lane, fs, stg);
+  else fast_epilogue<EPI_NONE, 1>(p, acc, row0, col0, lane, fs, stg);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 256x256x32 variant: twice the arithmetic intensity of the 256x128 tile (128 flop per staged byte, the L2->LDS
+// stream is what bounds the smaller tile), 8 waves as 2 (M) x 4 (N) with 128x64 per wave (acc[8][4]), a 4-slot ring
+// of 32-KiB K-slices with THREE slices in flight, one raw s_barrier per K-step of 32 MFMAs per wave.
+// k-major rows are 64 B here: 16-B chunk c of row r is stored at c ^ G(r), G(r) = (-(r >> 2)) & 3 (conflict-free
+// for the ds_read_b128 lane groups); transposed operands use the same 32-B column-block swizzle as above.
+#define GBM 256
+#define GBN 256
+#define GBK 32
+#define G_OP_STAGE (256 * 64)              // 16 KiB per operand per slot
+#define G_STAGE (2 * G_OP_STAGE)
+#define G_SLOTS 4
+
+template <bool TRANS>
+__device__ __forceinline__ void dma_tile32(const bf16* __restrict__ X, int ld, int r0, int k0, char* lds, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int blk = wave * 2 + i;                        // 16 blocks of 1 KiB
+    const bf16* src;
+    if (!TRANS) {
+      const int row = blk * 16 + (lane >> 2), pos = lane & 3;
+      const int c = pos ^ ((-(row >> 2)) & 3);
+      src = X + (size_t)(r0 + row) * ld + k0 + c * 8;
+    } else {
+      const int k = blk * 2 + (lane >> 5), pc = lane & 31;          // 512-B k-rows, 32 chunks each
+      const int c = (((pc >> 1) ^ ftr_key(k)) << 1) | (pc & 1);
+      src = X + (size_t)(k0 + k) * ld + r0 + c * 8;
+    }
+    __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(lds + blk * 1024), 16, 0, 0);
+  }
+}
+
+template <bool TRANS>
+__device__ __forceinline__ bf8 gfrag(const char* lds, int rbase, int lane) {
+  if (!TRANS) {
+    const int row = rbase + (lane & 15), kc = lane >> 4;
+    return *reinterpret_cast<const bf8*>(lds + row * 64 + ((kc ^ ((-(row >> 2)) & 3)) << 4));
+  } else {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int k = 8 * g + q;
+    const int off = k * 512 + (((rbase >> 4) ^ ftr_key(k)) << 5) + p * 8;
+    s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(lds + off));
+    s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(lds + off + 4 * 512));
+    s8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(bf8, r);
+  }
+}
+
+template <bool TA, bool TB_KMAJOR>
+__global__ __launch_bounds__(512, 2) void gemm_fast256_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;               // 2 x 4 waves, 128 x 64 each
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int nwg = ntiles * p.splits;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int split = wg / ntiles, tile = wg - split * ntiles;
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const int m0 = tm * GBM, n0 = tn * GBN;
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg) / GBK;
+
+  f4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+    if (t < nk) {
+      dma_tile32<TA>(p.A, p.lda, m0, kbeg + t * GBK, smem + t * G_STAGE, wave, lane);
+      dma_tile32<!TB_KMAJOR>(p.B, p.ldb, n0, kbeg + t * GBK, smem + t * G_STAGE + G_OP_STAGE, wave, lane);
+    }
+  int slot = 0;
+  for (int t = 0; t < nk; ++t) {
+    // 4 LDS-DMA instructions per wave per slice; slices t+1, t+2 may stay in flight
+    const int ahead = nk - 1 - t;
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 3 < nk) {
+      const int ns = (slot + 3) & 3;
+      dma_tile32<TA>(p.A, p.lda, m0, kbeg + (t + 3) * GBK, smem + ns * G_STAGE, wave, lane);
+      dma_tile32<!TB_KMAJOR>(p.B, p.ldb, n0, kbeg + (t + 3) * GBK, smem + ns * G_STAGE + G_OP_STAGE, wave, lane);
+    }
+    const char* la = smem + slot * G_STAGE;
+    const char* lb = la + G_OP_STAGE;
+    bf8 af[8], bfr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = gfrag<!TB_KMAJOR>(lb, wn * 64 + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = gfrag<TA>(la, wm * 128 + i * 16, lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    slot = (slot + 1) & 3;
+  }
+  const bool fs = split == 0;
+  float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();          // ring (first pass) / previous staging pass fully consumed
+    f4 (&a4)[4][4] = *reinterpret_cast<f4 (*)[4][4]>(&acc[half * 4][0]);
+    const int row0 = m0 + wm * 128 + half * 64, col0 = n0 + wn * 64;
+    if (!p.c_f32) fast_epilogue_epi<0>(p, a4, row0, col0, lane, fs, stg);
+    else if (p.atomic) fast_epilogue<EPI_NONE, 3>(p, a4, row0, col0, lane, fs, stg);
+    else if (p.accum) fast_epilogue<EPI_NONE, 2>(p, a4, row0, col0, lane, fs, stg);
+    else if (p.epi == EPI_TANH) fast_epilogue<EPI_TANH, 1>(p, a4, row0, col0, lane, fs, stg);
+    else fast_epilogue<EPI_NONE, 1>(p, a4, row0, col0, lane, fs, stg);
+  }
+}
+
+static bool fast256_eligible(const GemmParams& p, int splits) {
+  if (p.M % GBM || p.N % GBN || p.K % GBK || p.k_per_split % GBK) return false;
+  return (p.M / GBM) * (p.N / GBN) * splits >= 128;        // enough blocks to fill the chip
+}
+
+static bool fast128_eligible(const GemmParams& p, int splits) {
+  if (p.M % FBM || p.N % FBN) return false;
+  if (p.K % FBK || p.k_per_split % FBK) return false;
+  return true;
+}
+
+bool gemm_fast_eligible(const GemmParams& p, int splits) {
+  if (p.c_f32 && !(p.epi == EPI_NONE || p.epi == EPI_TANH)) return false;   // f32 outputs: plain / tanh only
+  if ((p.ldc % 4) || (p.ld_aux % 4)) return false;
+  if ((long long)p.k_per_split * splits < p.K) return false;
+  return fast256_eligible(p, splits) || fast128_eligible(p, splits);
+}
+
+static int use256() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MMSIM_GEMM_TILE"); v = (e && e[0] == '1') ? 0 : 1; }   // MMSIM_GEMM_TILE=128: 256x128 only
+  return v;
+}
+
+void gemm_fast_launch(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s) {
+  // wgrad-shaped products (A transposed, long reduction, few output tiles) keep the 256x128 tile: more tiles per split
+  const bool prefer256 = use256() && !trans_a;
+  if ((prefer256 || !fast128_eligible(p, splits)) && fast256_eligible(p, splits)) {
+    p.tiles_m = p.M / GBM; p.tiles_n = p.N / GBN; p.splits = splits;
+    dim3 grid(p.tiles_m * p.tiles_n * splits), block(512);
+    const size_t lds = 8 * 64 * EP_PITCH * 4;            // 136 KiB: the epilogue staging (8 waves x 64 x 68 floats) exceeds the 128-KiB ring
+    static bool done256 = false;
+    if (!done256) {
+      (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      done256 = true;
+    }
+    if (!trans_a && b_kmajor) hipLaunchKernelGGL((gemm_fast256_kernel<false, true>), grid, block, lds, s, p);
+    else if (!trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_fast256_kernel<false, false>), grid, block, lds, s, p);
+    else if (trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_fast256_kernel<true, false>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((gemm_fast256_kernel<true, true>), grid, block, lds, s, p);
+    return;
+  }
+  p.tiles_m = p.M / FBM; p.tiles_n = p.N / FBN;
+  p.splits = splits;
+  dim3 grid(p.tiles_m * p.tiles_n * splits), block(512);
+  const size_t lds = 3 * F_STAGE;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_fast_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_fast_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_fast_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_fast_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  if (!trans_a && b_kmajor) hipLaunchKernelGGL((gemm_fast_kernel<false, true>), grid, block, lds, s, p);
+  else if (!trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_fast_kernel<false, false>), grid, block, lds, s, p);
+  else if (trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_fast_kernel<true, false>), grid, block, lds, s, p);
+  else hipLaunchKernelGGL((gemm_fast_kernel<true, true>), grid, block, lds, s, p);
+}

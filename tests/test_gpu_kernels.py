@@ -27,7 +27,11 @@ def rnd(*s, scale=1.0, seed=0):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 136, 72), (1000, 40, 128), (8, 1000, 768),
-                                   (513, 257, 1032)])
+                                   (513, 257, 1032),
+                                   # tile-aligned shapes take the LDS-DMA fast path (256x128x64 tiles)
+                                   (256, 128, 64), (512, 384, 192), (1024, 256, 1024), (768, 1280, 128),
+                                   # ... and with >= 128 tiles of 256x256 the 256x256x32 kernel (1, 2, 3, 5 K-slices: ring edge cases)
+                                   (8192, 1024, 32), (8192, 1024, 64), (8192, 1024, 96), (4096, 2048, 160)])
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
 def test_gemm_layouts(M, N, K, layout):
     ops = _ops()
