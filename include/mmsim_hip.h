@@ -114,8 +114,11 @@ int mmsim_tanh_bwd(const float* dpooled, const float* pooled, void* dpre, unsign
 /* ---- EfficientNet image tower (timm efficientnet_b0/b4 under cv_classifier.py:23-27,49), NHWC bf16 activations.
  * Train-mode BatchNorm2d (eps 1e-5, momentum 0.1): bn_stats accumulates per-channel sum / sum of squares into
  * sums [2][C] (fp32, pre-zeroed); bn_finalize turns them into mean, rstd, scale = gamma*rstd,
- * shift = beta - mean*scale and updates the running statistics; bn_apply writes act(scale*z+shift) (+resid). */
-int mmsim_bn_stats(const void* z, float* sums, int P, int C, void* stream);
+ * shift = beta - mean*scale and updates the running statistics; bn_apply writes act(scale*z+shift) (+resid).
+ * Per-channel reductions write per-block partial slabs into `scratch` (fp32, >= 4M floats is always enough for
+ * the supported towers; each call states its need in the error message) and sum them with a second tiny launch:
+ * results are bitwise reproducible and no launch leaves a thousand blocks queueing on the same atomic address. */
+int mmsim_bn_stats(const void* z, float* sums, int P, int C, float* scratch, unsigned long long scratch_floats, void* stream);
 int mmsim_bn_finalize(const float* sums, const float* gamma, const float* beta, float* mean, float* rstd, float* scale,
                       float* shift, float* run_mean, float* run_var, int C, float count, float eps, float momentum,
                       void* stream);
@@ -135,7 +138,8 @@ int mmsim_se_mlp_bwd(const float* dgate, const float* gate, const float* hr, con
  * sums [2][C] must be zero on entry unless sums_ready (already produced by mmsim_dwconv_bwd_data). */
 int mmsim_bn_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* scale,
                  const float* shift, const float* gate, const float* dsq, int hw, int act_silu, float* sums,
-                 int sums_ready, void* dz, float* dgamma, float* dbeta, int P, int C, void* stream);
+                 int sums_ready, void* dz, float* dgamma, float* dbeta, int P, int C, float* scratch,
+                 unsigned long long scratch_floats, void* stream);
 /* Depthwise k3/k5 stride 1/2 conv, pad k/2.  Weights in tap-major fp32 [K*K][C] (see the two converters).
  * fwd also accumulates the output's BN sums; bwd_data also applies silu'(bn(z1)) of the producer and
  * accumulates that BatchNorm's backward sums (z1 == NULL: plain transposed conv, + resid if given);
@@ -143,14 +147,16 @@ int mmsim_bn_bwd(const void* dy, const void* z, const float* mean, const float* 
 int mmsim_dw_weight_to_tap_major(const float* w, float* wT, int C, int K, void* stream);
 int mmsim_dw_grad_from_tap_major(const float* gT, float* g, int C, int K, void* stream);
 int mmsim_dwconv_fwd(const void* a, const float* w_tap_major, void* z, float* sums, int B, int Hi, int Wi, int C, int K,
-                     int S, void* stream);
+                     int S, float* scratch, unsigned long long scratch_floats, void* stream);
 int mmsim_dwconv_bwd_data(const void* dz, const float* w_tap_major, const void* z1, const float* mean, const float* rstd,
                           const float* scale, const float* shift, const void* resid, void* dpre, float* sums, int B,
-                          int Hi, int Wi, int C, int K, int S, void* stream);
+                          int Hi, int Wi, int C, int K, int S, float* scratch, unsigned long long scratch_floats,
+                          void* stream);
 int mmsim_dwconv_bwd_weight(const void* dz, const void* a, float* g_tap_major, int B, int Hi, int Wi, int C, int K, int S,
-                            void* stream);
+                            float* scratch, unsigned long long scratch_floats, void* stream);
 /* Stem: 3x3 stride-2 pad-1 conv on the NCHW fp32 image -> NHWC bf16, with the output's BN sums; and its wgrad. */
-int mmsim_stem_fwd(const float* x, const float* w, void* z, float* sums, int B, int Hi, int Wi, int Co, void* stream);
+int mmsim_stem_fwd(const float* x, const float* w, void* z, float* sums, int B, int Hi, int Wi, int Co, float* scratch,
+                   unsigned long long scratch_floats, void* stream);
 int mmsim_stem_wgrad(const void* dz, const float* x, float* dw, int B, int Hi, int Wi, int Co, void* stream);
 /* Tower top (cv_classifier.py:50-54): dropout -> bf16, BatchNorm1d on fp32 [B,C], pool backward broadcast. */
 int mmsim_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

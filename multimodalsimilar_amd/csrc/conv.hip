@@ -24,11 +24,13 @@ __device__ __forceinline__ CgMap cg_map(int C) {
 }
 static inline int cg_grid_y(int C) { const int G = C >> 3; return G >= 256 ? (G + 255) / 256 : 1; }
 
-// reduce acc[NV] over the row-lanes of a block (same channel octet) and atomically add into dst
-// (dst[i] base for value i: dst_i = base + (i/8)*stat_stride + c0 + i%8)
+// Reduce acc[NV] over the row-lanes of a block (same channel octet) and STORE the block's partial result:
+// value i goes to base[(i/8)*stat_stride + c0 + i%8], base = this block's slot of a [nparts][...] scratch.
+// A second tiny kernel (reduce_partials) sums the slots: a thousand blocks atomically adding into the same few
+// hundred addresses serialise at the memory side (~230 us per call measured) -- partial slabs do not.
 template <int NV>
-__device__ __forceinline__ void block_reduce_atomic(float (&acc)[NV], const CgMap& m, float* lds, float* base,
-                                                    size_t stat_stride) {
+__device__ __forceinline__ void block_reduce_store(float (&acc)[NV], const CgMap& m, float* lds, float* base,
+                                                   size_t stat_stride) {
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < NV; ++i) lds[threadIdx.x * NV + i] = acc[i];
@@ -38,7 +40,7 @@ __device__ __forceinline__ void block_reduce_atomic(float (&acc)[NV], const CgMa
 #pragma unroll
       for (int i = 0; i < NV; ++i) acc[i] += lds[(m.cg + r * m.G) * NV + i];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) atomicAdd(base + (size_t)(i >> 3) * stat_stride + m.cg * 8 + (i & 7), acc[i]);
+    for (int i = 0; i < NV; ++i) base[(size_t)(i >> 3) * stat_stride + m.cg * 8 + (i & 7)] = acc[i];
   }
 }
 
@@ -58,8 +60,27 @@ __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
   f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
 
+// out[i] (+)= sum_p parts[p*n + i]
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ parts, int nparts, int n, float* out,
+                                                              int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int p = 0;
+  for (; p + 3 < nparts; p += 4) {
+    a0 += parts[(size_t)p * n + i]; a1 += parts[(size_t)(p + 1) * n + i];
+    a2 += parts[(size_t)(p + 2) * n + i]; a3 += parts[(size_t)(p + 3) * n + i];
+  }
+  for (; p < nparts; ++p) a0 += parts[(size_t)p * n + i];
+  const float v = (a0 + a1) + (a2 + a3);
+  out[i] = accumulate ? out[i] + v : v;
+}
+static void launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, parts, nparts, n, out, accumulate);
+}
+
 // ------------------------------------------------------------------ BN statistics
-__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* z, float* sums, int P, int C, int rows_per_block) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* __restrict__ z, float* parts, int P, int C, int rows_per_block) {
   __shared__ float lds[256 * 16];
   const CgMap m = cg_map(C);
   float acc[16];
@@ -67,6 +88,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* z, float* sum
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   if (m.active) {
     const int r0 = blockIdx.x * rows_per_block, r1 = min(P, r0 + rows_per_block);
+#pragma unroll 4
     for (int r = r0 + m.rl; r < r1; r += m.nr) {
       float f[8];
       unpack8(*reinterpret_cast<const uint4*>(z + (size_t)r * C + m.cg * 8), f);
@@ -74,7 +96,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* z, float* sum
       for (int e = 0; e < 8; ++e) { acc[e] += f[e]; acc[8 + e] += f[e] * f[e]; }
     }
   }
-  block_reduce_atomic<16>(acc, m, lds, sums, (size_t)C);
+  block_reduce_store<16>(acc, m, lds, parts + (size_t)blockIdx.x * 2 * C, (size_t)C);
 }
 
 // sums [2][C] -> mean, rstd, scale = gamma*rstd, shift = beta - mean*scale; running stats (momentum, unbiased var)
@@ -255,7 +277,7 @@ __device__ __forceinline__ void bn_bwd_elem(const BnBwd& p, int r, int c0, float
   for (int e = 0; e < 8; ++e) { da[e] = d[e]; zh[e] = (z[e] - mu[e]) * rs[e]; }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwd p, float* sums, int rows_per_block) {
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwd p, float* parts, int rows_per_block) {
   __shared__ float lds[256 * 16];
   const CgMap m = cg_map(p.C);
   float acc[16];
@@ -270,7 +292,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwd p, float* sums
       for (int e = 0; e < 8; ++e) { acc[e] += da[e]; acc[8 + e] += da[e] * zh[e]; }
     }
   }
-  block_reduce_atomic<16>(acc, m, lds, sums, (size_t)p.C);
+  block_reduce_store<16>(acc, m, lds, parts + (size_t)blockIdx.x * 2 * p.C, (size_t)p.C);
 }
 
 // dz = scale * (da - S1/P - zh*S2/P); block 0 also does dgamma += S2, dbeta += S1
@@ -311,7 +333,7 @@ struct DwGeom { int B, Hi, Wi, Ho, Wo, C; };
 // forward: a [B,Hi,Wi,C] -> z [B,Ho,Wo,C]; fused per-channel sum / sumsq of z (bf16-rounded) for the next BN.
 // thread = (octet, strip of TW output pixels along W)
 template <int K, int S>
-__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* a, const float* wT, bf16* z, float* sums, DwGeom g,
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* __restrict__ a, const float* __restrict__ wT, bf16* z, float* parts, DwGeom g,
                                                          int items_per_block) {
   constexpr int TW = 4, PAD = K / 2, NIN = (TW - 1) * S + K;
   __shared__ float lds[256 * 16];
@@ -368,7 +390,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* a, const fl
       }
     }
   }
-  block_reduce_atomic<16>(st, m, lds, sums, (size_t)g.C);
+  block_reduce_store<16>(st, m, lds, parts + (size_t)blockIdx.x * 2 * g.C, (size_t)g.C);
 }
 
 // backward data: da[b,hi,wi,c] = sum_{kh,kw} dz[b,(hi+PAD-kh)/S,(wi+PAD-kw)/S,c] * w[kh,kw,c]   (divisible taps only)
@@ -377,7 +399,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* a, const fl
 template <int K, int S>
 __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const bf16* dz, const float* wT, const bf16* z1, const float* mean,
                                                               const float* rstd, const float* scale, const float* shift,
-                                                              const bf16* resid, bf16* out, float* sums, DwGeom g,
+                                                              const bf16* resid, bf16* out, float* parts, DwGeom g,
                                                               int items_per_block) {
   constexpr int TW = 4, PAD = K / 2;
   __shared__ float lds[256 * 16];
@@ -454,12 +476,12 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const bf16* dz, co
       }
     }
   }
-  if (z1) block_reduce_atomic<16>(st, m, lds, sums, (size_t)g.C);
+  if (z1) block_reduce_store<16>(st, m, lds, parts + (size_t)blockIdx.x * 2 * g.C, (size_t)g.C);
 }
 
 // backward weight (tap-major gT [K*K][C]): one kernel row kh per blockIdx.z; thread = (octet, output row lane)
 template <int K, int S>
-__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16* dz, const bf16* a, float* gT, DwGeom g,
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16* __restrict__ dz, const bf16* __restrict__ a, float* parts, DwGeom g,
                                                                 int rows_per_block) {
   constexpr int PAD = K / 2;
   __shared__ float lds[256 * 8 * K];
@@ -493,12 +515,12 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16* dz, 
       }
     }
   }
-  block_reduce_atomic<8 * K>(acc, m, lds, gT + (size_t)kh * K * g.C, (size_t)g.C);
+  block_reduce_store<8 * K>(acc, m, lds, parts + ((size_t)blockIdx.x * K + kh) * K * g.C, (size_t)g.C);
 }
 
 // ------------------------------------------------------------------ stem conv 3x3 s2 p1 on the NCHW fp32 image
 struct StemGeom { int B, Hi, Wi, Ho, Wo, Co; };
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const float* w, bf16* z, float* sums, StemGeom g,
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, bf16* z, float* parts, StemGeom g,
                                                        int pix_per_block) {
   __shared__ float lds[256 * 16];
   __shared__ float wl[27 * 64];              // [tap][co], Co <= 64
@@ -541,7 +563,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const flo
       for (int e = 0; e < 8; ++e) { st[e] += r[e]; st[8 + e] += r[e] * r[e]; }
     }
   }
-  block_reduce_atomic<16>(st, m, lds, sums, (size_t)g.Co);
+  block_reduce_store<16>(st, m, lds, parts + (size_t)blockIdx.x * 2 * g.Co, (size_t)g.Co);
 }
 
 // dW[co][ci][kh][kw] += sum_p dz[p,co] * x[p @ tap]; thread = (tap, octet), loops over the block's pixel slab
@@ -647,11 +669,16 @@ static int rows_per_block_for(int P, int nr) {
 }
 static int nr_of(int C) { const int G = C >> 3; return G >= 256 ? 1 : 256 / G; }
 
-extern "C" int mmsim_bn_stats(const void* z, float* sums, int P, int C, void* stream) {
+#define REQ_SCRATCH(need, name) MMSIM_REQUIRE(scratch && scratch_floats >= (unsigned long long)(need), name ": scratch too small")
+
+extern "C" int mmsim_bn_stats(const void* z, float* sums, int P, int C, float* scratch, unsigned long long scratch_floats,
+                              void* stream) {
   MMSIM_REQUIRE(z && sums && P > 0, "bn_stats: bad arguments"); REQ_C8(C, "bn_stats");
   const int rpb = rows_per_block_for(P, nr_of(C));
-  hipLaunchKernelGGL(bn_stats_kernel, dim3((P + rpb - 1) / rpb, cg_grid_y(C)), dim3(256), 0, (hipStream_t)stream, (const bf16*)z,
-                     sums, P, C, rpb);
+  const int nparts = (P + rpb - 1) / rpb;
+  REQ_SCRATCH((size_t)nparts * 2 * C, "bn_stats");
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nparts, cg_grid_y(C)), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scratch, P, C, rpb);
+  launch_reduce(scratch, nparts, 2 * C, sums, 0, (hipStream_t)stream);
   return mmsim_check_launch("bn_stats");
 }
 
@@ -710,16 +737,20 @@ static BnBwd mk_bnbwd(const void* dy, const void* z, const float* mean, const fl
   return p;
 }
 
-/* sums [2][C] must be zero on entry */
 extern "C" int mmsim_bn_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* scale,
                             const float* shift, const float* gate, const float* dsq, int hw, int act_silu, float* sums,
-                            int sums_ready, void* dz, float* dgamma, float* dbeta, int P, int C, void* stream) {
+                            int sums_ready, void* dz, float* dgamma, float* dbeta, int P, int C, float* scratch,
+                            unsigned long long scratch_floats, void* stream) {
   MMSIM_REQUIRE(dy && z && mean && rstd && scale && shift && sums && dz && P > 0, "bn_bwd: bad arguments"); REQ_C8(C, "bn_bwd");
   MMSIM_REQUIRE((gate == nullptr) == (dsq == nullptr), "bn_bwd: gate and dsq come together");
   const BnBwd p = mk_bnbwd(dy, z, mean, rstd, scale, shift, gate, dsq, hw, act_silu, P, C);
   const int rpb = rows_per_block_for(P, nr_of(C));
   dim3 grid((P + rpb - 1) / rpb, cg_grid_y(C));
-  if (!sums_ready) hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, sums, rpb);
+  if (!sums_ready) {
+    REQ_SCRATCH((size_t)grid.x * 2 * C, "bn_bwd");
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, scratch, rpb);
+    launch_reduce(scratch, grid.x, 2 * C, sums, 0, (hipStream_t)stream);
+  }
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, sums, (bf16*)dz, dgamma, dbeta, rpb);
   return mmsim_check_launch("bn_bwd");
 }
@@ -749,19 +780,22 @@ static int dw_check(int B, int Hi, int Wi, int C, int K, int S, DwGeom* g) {
   else hipLaunchKernelGGL((KERNEL<5, 2>), __VA_ARGS__);
 
 extern "C" int mmsim_dwconv_fwd(const void* a, const float* w_tap_major, void* z, float* sums, int B, int Hi, int Wi, int C, int K,
-                                int S, void* stream) {
+                                int S, float* scratch, unsigned long long scratch_floats, void* stream) {
   DwGeom g; int rc = dw_check(B, Hi, Wi, C, K, S, &g); if (rc) return rc;
   MMSIM_REQUIRE(a && w_tap_major && z && sums, "dwconv_fwd: null operand");
   const int nitems = B * g.Ho * ((g.Wo + 3) / 4);
   const int ipb = rows_per_block_for(nitems, nr_of(C));
   dim3 grid((nitems + ipb - 1) / ipb, cg_grid_y(C));
-  DW_DISPATCH(dwconv_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)a, w_tap_major, (bf16*)z, sums, g, ipb)
+  REQ_SCRATCH((size_t)grid.x * 2 * C, "dwconv_fwd");
+  DW_DISPATCH(dwconv_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)a, w_tap_major, (bf16*)z, scratch, g, ipb)
+  launch_reduce(scratch, grid.x, 2 * C, sums, 0, (hipStream_t)stream);
   return mmsim_check_launch("dwconv_fwd");
 }
 
 extern "C" int mmsim_dwconv_bwd_data(const void* dz, const float* w_tap_major, const void* z1, const float* mean, const float* rstd,
                                      const float* scale, const float* shift, const void* resid, void* dpre, float* sums, int B,
-                                     int Hi, int Wi, int C, int K, int S, void* stream) {
+                                     int Hi, int Wi, int C, int K, int S, float* scratch, unsigned long long scratch_floats,
+                                     void* stream) {
   DwGeom g; int rc = dw_check(B, Hi, Wi, C, K, S, &g); if (rc) return rc;
   MMSIM_REQUIRE(dz && w_tap_major && dpre, "dwconv_bwd_data: null operand");
   MMSIM_REQUIRE(!z1 || (mean && rstd && scale && shift && sums), "dwconv_bwd_data: fused BN+SiLU backward needs the BN state");
@@ -769,29 +803,37 @@ extern "C" int mmsim_dwconv_bwd_data(const void* dz, const float* w_tap_major, c
   const int nitems = B * Hi * ((Wi + 3) / 4);
   const int ipb = rows_per_block_for(nitems, nr_of(C));
   dim3 grid((nitems + ipb - 1) / ipb, cg_grid_y(C));
+  if (z1) REQ_SCRATCH((size_t)grid.x * 2 * C, "dwconv_bwd_data");
   DW_DISPATCH(dwconv_bwd_data_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, w_tap_major, (const bf16*)z1, mean,
-              rstd, scale, shift, (const bf16*)resid, (bf16*)dpre, sums, g, ipb)
+              rstd, scale, shift, (const bf16*)resid, (bf16*)dpre, scratch, g, ipb)
+  if (z1) launch_reduce(scratch, grid.x, 2 * C, sums, 0, (hipStream_t)stream);
   return mmsim_check_launch("dwconv_bwd_data");
 }
 
 extern "C" int mmsim_dwconv_bwd_weight(const void* dz, const void* a, float* g_tap_major, int B, int Hi, int Wi, int C, int K, int S,
-                                       void* stream) {
+                                       float* scratch, unsigned long long scratch_floats, void* stream) {
   DwGeom g; int rc = dw_check(B, Hi, Wi, C, K, S, &g); if (rc) return rc;
   MMSIM_REQUIRE(dz && a && g_tap_major, "dwconv_bwd_weight: null operand");
   const int nrows = B * g.Ho;
-  int rpb = (nrows + 255) / 256; const int nr = nr_of(C); if (rpb < nr) rpb = nr;
+  int rpb = (nrows + 127) / 128; const int nr = nr_of(C); if (rpb < nr) rpb = nr;
   dim3 grid((nrows + rpb - 1) / rpb, cg_grid_y(C), K);
-  DW_DISPATCH(dwconv_bwd_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, (const bf16*)a, g_tap_major, g, rpb)
+  REQ_SCRATCH((size_t)grid.x * K * K * C, "dwconv_bwd_weight");
+  DW_DISPATCH(dwconv_bwd_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, (const bf16*)a, scratch, g, rpb)
+  launch_reduce(scratch, grid.x, K * K * C, g_tap_major, 1, (hipStream_t)stream);      /* g_tap_major += */
   return mmsim_check_launch("dwconv_bwd_weight");
 }
 
-extern "C" int mmsim_stem_fwd(const float* x, const float* w, void* z, float* sums, int B, int Hi, int Wi, int Co, void* stream) {
+extern "C" int mmsim_stem_fwd(const float* x, const float* w, void* z, float* sums, int B, int Hi, int Wi, int Co, float* scratch,
+                              unsigned long long scratch_floats, void* stream) {
   MMSIM_REQUIRE(x && w && z && sums && B > 0 && Hi > 1 && Wi > 1, "stem_fwd: bad arguments"); REQ_C8(Co, "stem_fwd");
   MMSIM_REQUIRE(Co <= 64, "stem_fwd: at most 64 output channels");
   StemGeom g; g.B = B; g.Hi = Hi; g.Wi = Wi; g.Ho = (Hi + 2 - 3) / 2 + 1; g.Wo = (Wi + 2 - 3) / 2 + 1; g.Co = Co;
   const int npix = B * g.Ho * g.Wo;
   const int ppb = rows_per_block_for(npix, nr_of(Co));
-  hipLaunchKernelGGL(stem_fwd_kernel, dim3((npix + ppb - 1) / ppb), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)z, sums, g, ppb);
+  const int nparts = (npix + ppb - 1) / ppb;
+  REQ_SCRATCH((size_t)nparts * 2 * Co, "stem_fwd");
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)z, scratch, g, ppb);
+  launch_reduce(scratch, nparts, 2 * Co, sums, 0, (hipStream_t)stream);
   return mmsim_check_launch("stem_fwd");
 }
 

@@ -217,6 +217,12 @@ class EfficientNet(nn.Module):
         st = self._run_forward(x)
         return st.pooled.clone()
 
+    SCRATCH_FLOATS = 8 << 20      # per-block partial slabs of the channel reductions (largest need: ~5.5 M floats)
+
+    def _scr(self):
+        t = self._buf("scratch", (self.SCRATCH_FLOATS,), torch.float32)
+        return t.data_ptr(), self.SCRATCH_FLOATS
+
     def _bnp(self, st, name, i):
         """per-BN fp32 scratch row i of (mean, rstd, scale, shift)."""
         o, c = self._bn_off[name], dict(self._bn_list)[name]
@@ -250,7 +256,7 @@ class EfficientNet(nn.Module):
             bs.z1 = E(P_in, b.mid)
             ops.gemm(cur, SV(n + ".conv_pw.weight", (b.mid, b.cin)), bs.z1)
             sm = self._sums(st, n + "." + e_bn, "f")
-            lib.bn_stats(bs.z1.data_ptr(), sm.data_ptr(), P_in, b.mid, s)
+            lib.bn_stats(bs.z1.data_ptr(), sm.data_ptr(), P_in, b.mid, *self._scr(), s)
             self._bn_finalize(st, n + "." + e_bn, sm, P_in)
             bs.a1 = E(P_in, b.mid)
             lib.bn_apply(bs.z1.data_ptr(), self._bnp(st, n + "." + e_bn, 2).data_ptr(),
@@ -263,7 +269,7 @@ class EfficientNet(nn.Module):
         lib.dw_weight_to_tap_major(V(n + ".conv_dw.weight").data_ptr(), bs.wT.data_ptr(), b.mid, b.k, s)
         bs.z2 = E(P_out, b.mid)
         sm = self._sums(st, n + "." + d_bn, "f")
-        lib.dwconv_fwd(bs.a1.data_ptr(), bs.wT.data_ptr(), bs.z2.data_ptr(), sm.data_ptr(), B, H, W, b.mid, b.k, b.stride, s)
+        lib.dwconv_fwd(bs.a1.data_ptr(), bs.wT.data_ptr(), bs.z2.data_ptr(), sm.data_ptr(), B, H, W, b.mid, b.k, b.stride, *self._scr(), s)
         self._bn_finalize(st, n + "." + d_bn, sm, P_out)
         sc2, sh2 = self._bnp(st, n + "." + d_bn, 2), self._bnp(st, n + "." + d_bn, 3)
         bs.s = E(B, b.mid, dt=torch.float32)
@@ -280,7 +286,7 @@ class EfficientNet(nn.Module):
         lib.gemm_bf16_xf(1, P_out, b.cout, b.mid, bs.z2.data_ptr(), b.mid, w3.data_ptr(), b.mid, bs.z3.data_ptr(), b.cout, 0,
                          sc2.data_ptr(), sh2.data_ptr(), bs.gate.data_ptr(), Ho * Wo, 1, 0, s)
         sm = self._sums(st, n + "." + p_bn, "f")
-        lib.bn_stats(bs.z3.data_ptr(), sm.data_ptr(), P_out, b.cout, s)
+        lib.bn_stats(bs.z3.data_ptr(), sm.data_ptr(), P_out, b.cout, *self._scr(), s)
         self._bn_finalize(st, n + "." + p_bn, sm, P_out)
         nxt = E(P_out, b.cout)
         lib.bn_apply(bs.z3.data_ptr(), self._bnp(st, n + "." + p_bn, 2).data_ptr(), self._bnp(st, n + "." + p_bn, 3).data_ptr(),
@@ -309,7 +315,7 @@ class EfficientNet(nn.Module):
         P = B * H * W
         st.z0 = E(P, a.stem)
         lib.stem_fwd(x.data_ptr(), V("conv_stem.weight").data_ptr(), st.z0.data_ptr(), self._sums(st, "bn1", "f").data_ptr(),
-                     B, Hi, Wi, a.stem, s)
+                     B, Hi, Wi, a.stem, *self._scr(), s)
         self._bn_finalize(st, "bn1", self._sums(st, "bn1", "f"), P)
         cur = E(P, a.stem)
         lib.bn_apply(st.z0.data_ptr(), self._bnp(st, "bn1", 2).data_ptr(), self._bnp(st, "bn1", 3).data_ptr(), None,
@@ -324,7 +330,7 @@ class EfficientNet(nn.Module):
         st.zh = E(P, a.head)
         ops.gemm(cur, SV("conv_head.weight", (a.head, a.last)), st.zh)
         sm = self._sums(st, "bn2", "f")
-        lib.bn_stats(st.zh.data_ptr(), sm.data_ptr(), P, a.head, s)
+        lib.bn_stats(st.zh.data_ptr(), sm.data_ptr(), P, a.head, *self._scr(), s)
         self._bn_finalize(st, "bn2", sm, P)
         st.pooled = E(B, a.head, dt=torch.float32)
         lib.pool_bn_act(st.zh.data_ptr(), self._bnp(st, "bn2", 2).data_ptr(), self._bnp(st, "bn2", 3).data_ptr(), None,
@@ -340,7 +346,7 @@ class EfficientNet(nn.Module):
                    self._bnp(st, name, 2).data_ptr(), self._bnp(st, name, 3).data_ptr(),
                    None if gate is None else gate.data_ptr(), None if dsq is None else dsq.data_ptr(), hw, int(act),
                    sums.data_ptr(), int(sums_ready), dz.data_ptr(), fl.gview(name + ".weight").data_ptr(),
-                   fl.gview(name + ".bias").data_ptr(), P, C, ops._stream())
+                   fl.gview(name + ".bias").data_ptr(), P, C, *self._scr(), ops._stream())
 
     def _block_bwd(self, st, b, bs, dx):
         """Backward of one MBConv block: dx = dLoss/d(block output) -> returns dLoss/d(block input); parameter
@@ -376,14 +382,15 @@ class EfficientNet(nn.Module):
         self._bn_bwd(st, n + "." + d_bn, da2g, bs.z2, P_out, b.mid, dz2, act=True, gate=bs.gate, dsq=ds, hw=Ho * Wo)
         del da2g
         gT = torch.zeros(b.k * b.k, b.mid, dtype=torch.float32, device=dev)
-        lib.dwconv_bwd_weight(dz2.data_ptr(), bs.a1.data_ptr(), gT.data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride, s)
+        lib.dwconv_bwd_weight(dz2.data_ptr(), bs.a1.data_ptr(), gT.data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride, *self._scr(), s)
         lib.dw_grad_from_tap_major(gT.data_ptr(), G(n + ".conv_dw.weight").data_ptr(), b.mid, b.k, s)
         if b.type == "ir":
             en = n + "." + e_bn
             dpre1 = E(P_in, b.mid)
             lib.dwconv_bwd_data(dz2.data_ptr(), bs.wT.data_ptr(), bs.z1.data_ptr(), self._bnp(st, en, 0).data_ptr(),
                                 self._bnp(st, en, 1).data_ptr(), self._bnp(st, en, 2).data_ptr(), self._bnp(st, en, 3).data_ptr(),
-                                None, dpre1.data_ptr(), self._sums(st, en, "b").data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride, s)
+                                None, dpre1.data_ptr(), self._sums(st, en, "b").data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride,
+                                    *self._scr(), s)
             dz1 = E(P_in, b.mid)
             self._bn_bwd(st, en, dpre1, bs.z1, P_in, b.mid, dz1, act=False, sums_ready=True)
             del dpre1
@@ -395,7 +402,8 @@ class EfficientNet(nn.Module):
         else:
             dx_in = E(P_in, b.cin)
             lib.dwconv_bwd_data(dz2.data_ptr(), bs.wT.data_ptr(), None, None, None, None, None,
-                                dx.data_ptr() if b.skip else None, dx_in.data_ptr(), None, B, Hn, Wn, b.mid, b.k, b.stride, s)
+                                dx.data_ptr() if b.skip else None, dx_in.data_ptr(), None, B, Hn, Wn, b.mid, b.k, b.stride,
+                                    *self._scr(), s)
         if self.grad_ready_hook:
             first = n + (".conv_pw.weight" if b.type == "ir" else ".conv_dw.weight")
             self.grad_ready_hook(fl, *fl.span(first, n + "." + p_bn + ".bias"))

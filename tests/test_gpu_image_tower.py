@@ -19,10 +19,19 @@ def rnd(*s, scale=1.0, seed=0):
     return (torch.randn(*s, generator=g) * scale).to(DEV)
 
 
+_SCR = {}
+
+
 def _lib():
     from multimodalsimilar_amd import ops
     from multimodalsimilar_amd._lib import lib
+    if "t" not in _SCR:
+        _SCR["t"] = torch.empty(8 << 20, device=DEV)
     return lib, ops._stream()
+
+
+def scr():
+    return _SCR["t"].data_ptr(), _SCR["t"].numel()
 
 
 def nhwc(x):      # [B,C,H,W] fp32 -> [B*H*W, C] bf16
@@ -49,7 +58,7 @@ def test_depthwise_conv_fwd_bwd(K, S, H, C):
     lib.dw_weight_to_tap_major(w.data_ptr(), wT.data_ptr(), C, K, s)
     z = torch.empty(B * Ho * Wo, C, dtype=torch.bfloat16, device=DEV)
     sums = torch.zeros(2 * C, device=DEV)
-    lib.dwconv_fwd(a.data_ptr(), wT.data_ptr(), z.data_ptr(), sums.data_ptr(), B, H, W, C, K, S, s)
+    lib.dwconv_fwd(a.data_ptr(), wT.data_ptr(), z.data_ptr(), sums.data_ptr(), B, H, W, C, K, S, *scr(), s)
     assert relerr(nchw(z, B, Ho, Wo), ref) < 1e-2
     zf = z.float()
     assert relerr(sums[:C], zf.sum(0)) < 1e-3 and relerr(sums[C:], (zf * zf).sum(0)) < 1e-3
@@ -60,7 +69,7 @@ def test_depthwise_conv_fwd_bwd(K, S, H, C):
     res = rnd(B * H * W, C, seed=4).bfloat16()
     dx = torch.empty(B * H * W, C, dtype=torch.bfloat16, device=DEV)
     lib.dwconv_bwd_data(dzb.data_ptr(), wT.data_ptr(), None, None, None, None, None, res.data_ptr(), dx.data_ptr(), None,
-                        B, H, W, C, K, S, s)
+                        B, H, W, C, K, S, *scr(), s)
     assert relerr(nchw(dx, B, H, W), xr.grad + nchw(res, B, H, W)) < 1e-2
     # fused with the producer's BN + SiLU backward
     z1 = rnd(B * H * W, C, seed=5).bfloat16()
@@ -68,7 +77,7 @@ def test_depthwise_conv_fwd_bwd(K, S, H, C):
     scale, shift = 1 + 0.1 * rnd(C, seed=8), 0.1 * rnd(C, seed=9)
     bsum = torch.zeros(2 * C, device=DEV)
     lib.dwconv_bwd_data(dzb.data_ptr(), wT.data_ptr(), z1.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(),
-                        shift.data_ptr(), None, dx.data_ptr(), bsum.data_ptr(), B, H, W, C, K, S, s)
+                        shift.data_ptr(), None, dx.data_ptr(), bsum.data_ptr(), B, H, W, C, K, S, *scr(), s)
     y = (z1.float() * scale + shift).requires_grad_(True)
     F.silu(y).backward(torch.ones_like(y))
     dpre = xr.grad.permute(0, 2, 3, 1).reshape(-1, C) * y.grad
@@ -78,7 +87,7 @@ def test_depthwise_conv_fwd_bwd(K, S, H, C):
     assert relerr(bsum[C:], (dxf * (z1.float() - mean) * rstd).sum(0)) < 2e-3
     # weight gradient
     gT = torch.zeros(K * K, C, device=DEV)
-    lib.dwconv_bwd_weight(dzb.data_ptr(), a.data_ptr(), gT.data_ptr(), B, H, W, C, K, S, s)
+    lib.dwconv_bwd_weight(dzb.data_ptr(), a.data_ptr(), gT.data_ptr(), B, H, W, C, K, S, *scr(), s)
     g = torch.ones(C, 1, K, K, device=DEV)
     lib.dw_grad_from_tap_major(gT.data_ptr(), g.data_ptr(), C, K, s)
     assert relerr(g - 1, wr.grad) < 1e-2
@@ -92,7 +101,7 @@ def test_batchnorm_stats_apply_backward(C, P):
     z = rnd(P, C, seed=1, scale=2.0).bfloat16()
     gamma, beta = 1 + 0.2 * rnd(C, seed=2), 0.2 * rnd(C, seed=3)
     sums = torch.zeros(2 * C, device=DEV)
-    lib.bn_stats(z.data_ptr(), sums.data_ptr(), P, C, s)
+    lib.bn_stats(z.data_ptr(), sums.data_ptr(), P, C, *scr(), s)
     mean, rstd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
     rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     lib.bn_finalize(sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(),
@@ -121,7 +130,7 @@ def test_batchnorm_stats_apply_backward(C, P):
     dz = torch.empty_like(z)
     dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     lib.bn_bwd(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-               gate.data_ptr(), extra.data_ptr(), HW, 1, bs.data_ptr(), 0, dz.data_ptr(), dg.data_ptr(), db.data_ptr(), P, C, s)
+               gate.data_ptr(), extra.data_ptr(), HW, 1, bs.data_ptr(), 0, dz.data_ptr(), dg.data_ptr(), db.data_ptr(), P, C, *scr(), s)
     assert relerr(dz, zr.grad) < 1.5e-2
     assert relerr(dg, g_.grad) < 5e-3 and relerr(db, b_.grad) < 5e-3
     dgate = torch.empty(B, C, device=DEV)
@@ -161,7 +170,7 @@ def test_stem_conv_and_transformed_pointwise_gemm():
     Ho, Wo = ref.shape[2:]
     z = torch.empty(B * Ho * Wo, Co, dtype=torch.bfloat16, device=DEV)
     sums = torch.zeros(2 * Co, device=DEV)
-    lib.stem_fwd(x.data_ptr(), w.data_ptr(), z.data_ptr(), sums.data_ptr(), B, H, W, Co, s)
+    lib.stem_fwd(x.data_ptr(), w.data_ptr(), z.data_ptr(), sums.data_ptr(), B, H, W, Co, *scr(), s)
     assert relerr(nchw(z, B, Ho, Wo), ref) < 1e-2
     assert relerr(sums[:Co], z.float().sum(0)) < 1e-3
     dz = nhwc(rnd(B, Co, Ho, Wo, seed=3))
