@@ -75,10 +75,12 @@ int mmsim_add_ln_fwd(const void* t, const void* resid, const float* gamma, const
                      float* mean, float* rstd, int M, int H, float eps, float dropout_p, unsigned long long seed,
                      unsigned int stream_id, void* stream);
 /* dh = dh_a (+ dh_b if not NULL).  dy: gradient of y (residual branch).  dt: gradient of t, written only when
- * dropout_p > 0 (otherwise dt == dy and the caller reuses dy).  dgamma/dbeta/dbias: fp32 [H], accumulated. */
+ * dropout_p > 0 (otherwise dt == dy and the caller reuses dy).  dgamma/dbeta/dbias: fp32 [H], accumulated.
+ * scratch: >= ceil(M/(4*ceil(M/2048)))*3*H floats for the per-block partial column sums. */
 int mmsim_ln_bwd(const void* dh_a, const void* dh_b, const void* y, const float* mean, const float* rstd,
                  const float* gamma, void* dy, void* dt, float* dgamma, float* dbeta, float* dbias, int M, int H,
-                 float dropout_p, unsigned long long seed, unsigned int stream_id, void* stream);
+                 float dropout_p, unsigned long long seed, unsigned int stream_id, float* scratch,
+                 unsigned long long scratch_floats, void* stream);
 
 /* out[n] += sum_m x[m,n]  (bias gradients) */
 int mmsim_colsum_bf16(const void* x, int ld, float* out, int M, int N, void* stream);

@@ -60,23 +60,27 @@ __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
   f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
 
-// out[i] (+)= sum_p parts[p*n + i]
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ parts, int nparts, int n, float* out,
-                                                              int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int p = 0;
-  for (; p + 3 < nparts; p += 4) {
-    a0 += parts[(size_t)p * n + i]; a1 += parts[(size_t)(p + 1) * n + i];
-    a2 += parts[(size_t)(p + 2) * n + i]; a3 += parts[(size_t)(p + 3) * n + i];
+// out[i] += sum_p parts[p*n + i].  Block = 64 outputs x 4 waves; the part range is strided over (gridDim.y x 4) waves,
+// reduced across the block's waves in LDS, and leaves as ONE atomic per output per block (gridDim.y <= 8 adders).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ parts, int nparts, int n, float* out) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float a0 = 0.f, a1 = 0.f;
+  if (i < n) {
+    const int step = gridDim.y * 4;
+    int p = blockIdx.y * 4 + wv;
+    for (; p + step < nparts; p += 2 * step) { a0 += parts[(size_t)p * n + i]; a1 += parts[(size_t)(p + step) * n + i]; }
+    if (p < nparts) a0 += parts[(size_t)p * n + i];
   }
-  for (; p < nparts; ++p) a0 += parts[(size_t)p * n + i];
-  const float v = (a0 + a1) + (a2 + a3);
-  out[i] = accumulate ? out[i] + v : v;
+  red[wv][lane] = a0 + a1;
+  __syncthreads();
+  if (wv == 0 && i < n) atomicAdd(out + i, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 static void launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, parts, nparts, n, out, accumulate);
+  if (!accumulate) (void)hipMemsetAsync(out, 0, (size_t)n * sizeof(float), s);
+  int gy = nparts / 16; if (gy > 8) gy = 8; if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 63) / 64, gy), dim3(256), 0, s, parts, nparts, n, out);
 }
 
 // ------------------------------------------------------------------ BN statistics
@@ -138,8 +142,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* z, const floa
 }
 
 // out[b,c] = mul * sum_hw act(scale*z+shift)[b,hw,c] * (other ? other[b,hw,c] : 1)      (fp32 [B,C])
-__global__ __launch_bounds__(256) void pool_bn_act_kernel(const bf16* z, const float* scale, const float* shift,
-                                                          const bf16* other, float* out, int HW, int C, int act, float mul) {
+__global__ __launch_bounds__(256) void pool_bn_act_kernel(const bf16* __restrict__ z, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const bf16* __restrict__ other,
+                                                          float* out, int HW, int C, int act, float mul, int rows_per_z) {
   __shared__ float lds[256 * 8];
   const CgMap m = cg_map(C);
   const int b = blockIdx.x;
@@ -149,7 +154,9 @@ __global__ __launch_bounds__(256) void pool_bn_act_kernel(const bf16* z, const f
   if (m.active) {
     float sc[8], sh[8];
     ld8f(scale + m.cg * 8, sc); ld8f(shift + m.cg * 8, sh);
-    for (int r = m.rl; r < HW; r += m.nr) {
+    const int rbeg = blockIdx.z * rows_per_z, rend = min(HW, rbeg + rows_per_z);
+#pragma unroll 2
+    for (int r = rbeg + m.rl; r < rend; r += m.nr) {
       const size_t off = ((size_t)b * HW + r) * C + m.cg * 8;
       float f[8];
       unpack8(*reinterpret_cast<const uint4*>(z + off), f);
@@ -173,7 +180,10 @@ __global__ __launch_bounds__(256) void pool_bn_act_kernel(const bf16* z, const f
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += lds[(m.cg + r * m.G) * 8 + e];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) out[(size_t)b * C + m.cg * 8 + e] = acc[e] * mul;
+    for (int e = 0; e < 8; ++e) {
+      if (gridDim.z == 1) out[(size_t)b * C + m.cg * 8 + e] = acc[e] * mul;
+      else atomicAdd(out + (size_t)b * C + m.cg * 8 + e, acc[e] * mul);
+    }
   }
 }
 
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* __restrict_
       for (int j = 0; j < TW; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
-#pragma unroll
+#pragma unroll 1
       for (int kh = 0; kh < K; ++kh) {
         const int hi = ho * S - PAD + kh;
         if (hi < 0 || hi >= g.Hi) continue;
@@ -422,6 +432,35 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const bf16* dz, co
       for (int j = 0; j < TW; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+      if constexpr (S == 1) {
+        // stride 1: a correlation with the flipped kernel.  One dz row segment (TW + K - 1 chunks) is loaded per kernel
+        // row and reused by all K taps of all TW outputs from registers.
+        constexpr int NIN = TW + K - 1;
+#pragma unroll 1
+        for (int kh = 0; kh < K; ++kh) {
+          const int ho = hi + PAD - kh;
+          if (ho < 0 || ho >= g.Ho) continue;
+          float in[NIN][8];
+#pragma unroll
+          for (int x = 0; x < NIN; ++x) {
+            const int wo = wi0 - PAD + x;
+            if (wo >= 0 && wo < g.Wo)
+              unpack8(*reinterpret_cast<const uint4*>(dz + (((size_t)b * g.Ho + ho) * g.Wo + wo) * g.C + c0), in[x]);
+            else
+#pragma unroll
+              for (int e = 0; e < 8; ++e) in[x][e] = 0.f;
+          }
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            float w[8];
+            ld8f(wT + (size_t)(kh * K + kw) * g.C + c0, w);
+#pragma unroll
+            for (int j = 0; j < TW; ++j)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[j][e] += in[j + K - 1 - kw][e] * w[e];
+          }
+        }
+      } else {
 #pragma unroll
       for (int kh = 0; kh < K; ++kh) {
         const int t = hi + PAD - kh;
@@ -445,6 +484,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const bf16* dz, co
             for (int e = 0; e < 8; ++e) acc[j][e] += d[e] * w[e];
           }
         }
+      }
       }
 #pragma unroll
       for (int j = 0; j < TW; ++j) {
@@ -704,8 +744,14 @@ extern "C" int mmsim_bn_apply(const void* z, const float* scale, const float* sh
 extern "C" int mmsim_pool_bn_act(const void* z, const float* scale, const float* shift, const void* other, float* out, int B,
                                  int HW, int C, int act_silu, float mul, void* stream) {
   MMSIM_REQUIRE(z && scale && shift && out && B > 0 && HW > 0, "pool_bn_act: bad arguments"); REQ_C8(C, "pool_bn_act");
-  hipLaunchKernelGGL(pool_bn_act_kernel, dim3(B, cg_grid_y(C)), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scale, shift,
-                     (const bf16*)other, out, HW, C, act_silu, mul);
+  // large feature maps: split the HW range over blockIdx.z so that more than B blocks stream (few adders per output)
+  int nz = 1;
+  const int nr = nr_of(C);
+  while (nz < 16 && HW / (nz * 2) >= 4 * nr && B * nz < 2048) nz *= 2;
+  const int rpz = (HW + nz - 1) / nz;
+  if (nz > 1) (void)hipMemsetAsync(out, 0, (size_t)B * C * sizeof(float), (hipStream_t)stream);
+  hipLaunchKernelGGL(pool_bn_act_kernel, dim3(B, cg_grid_y(C), nz), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scale, shift,
+                     (const bf16*)other, out, HW, C, act_silu, mul, rpz);
   return mmsim_check_launch("pool_bn_act");
 }
 

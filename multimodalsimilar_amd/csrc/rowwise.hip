@@ -210,10 +210,27 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16* t, const bf
 // LayerNorm backward.  dh = dh_a (+ dh_b).  Outputs dy (gradient of the pre-LN sum: goes to the residual
 // branch) and dt = dropout-mask(dy) (gradient of the dense output; same buffer as dy when p == 0), plus
 // column sums: dgamma, dbeta, dbias (= colsum dt).
+// out[i] += sum_p parts[p*part_stride + i]  (64 outputs x 4 waves per block; gridDim.y part-chunks, one atomic each)
+__global__ __launch_bounds__(256) void row_reduce_partials_kernel(const float* __restrict__ parts, int nparts, size_t part_stride,
+                                                                  int n, float* out) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float a0 = 0.f, a1 = 0.f;
+  if (i < n) {
+    const int step = gridDim.y * 4;
+    int p = blockIdx.y * 4 + wv;
+    for (; p + step < nparts; p += 2 * step) { a0 += parts[(size_t)p * part_stride + i]; a1 += parts[(size_t)(p + step) * part_stride + i]; }
+    if (p < nparts) a0 += parts[(size_t)p * part_stride + i];
+  }
+  red[wv][lane] = a0 + a1;
+  __syncthreads();
+  if (wv == 0 && i < n) atomicAdd(out + i, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+}
+
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dh_a, const bf16* dh_b, const bf16* y, const float* mean_i,
                                                      const float* rstd_i, const float* gamma, bf16* dy, bf16* dt,
-                                                     float* dgamma, float* dbeta, float* dbias, int M, int H, int rows_per_wave,
-                                                     Drop dr) {
+                                                     float* parts, int M, int H, int rows_per_wave, Drop dr) {
   __shared__ float red[3][4][64 * 4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r0 = (blockIdx.x * 4 + wv) * rows_per_wave, r1 = min(M, r0 + rows_per_wave);
@@ -260,7 +277,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dh_a, const bf1
       }
     }
   }
-  // cross-wave reduction through LDS, then one atomic per column per block
+  // cross-wave reduction through LDS, then the block's partial column sums go to its slot parts[blockIdx.x][3][H]
+  // (a second launch sums the slots: hundreds of blocks adding atomically into the same H addresses serialise)
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
     const int col = lane * 4 + c * 256;
@@ -272,16 +290,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dh_a, const bf1
     *r0p = ag[c]; *r1p = ab[c]; *r2p = abias[c];
     __syncthreads();
     if (wv < 3 && col < H) {
-      float* dst = wv == 0 ? dgamma : (wv == 1 ? dbeta : dbias);
-      if (dst) {
-        float4 a = make_float4(0, 0, 0, 0);
+      float4 a = make_float4(0, 0, 0, 0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float4 b = *reinterpret_cast<const float4*>(&red[wv][k][lane * 4]);
-          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        }
-        atomicAdd(dst + col, a.x); atomicAdd(dst + col + 1, a.y); atomicAdd(dst + col + 2, a.z); atomicAdd(dst + col + 3, a.w);
+      for (int k = 0; k < 4; ++k) {
+        const float4 b = *reinterpret_cast<const float4*>(&red[wv][k][lane * 4]);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
       }
+      *reinterpret_cast<float4*>(parts + ((size_t)blockIdx.x * 3 + wv) * H + col) = a;
     }
   }
 }
@@ -406,16 +421,24 @@ extern "C" int mmsim_add_ln_fwd(const void* t, const void* resid, const float* g
 
 extern "C" int mmsim_ln_bwd(const void* dh_a, const void* dh_b, const void* y, const float* mean, const float* rstd,
                             const float* gamma, void* dy, void* dt, float* dgamma, float* dbeta, float* dbias, int M, int H,
-                            float dropout_p, unsigned long long seed, unsigned int stream_id, void* stream) {
+                            float dropout_p, unsigned long long seed, unsigned int stream_id, float* scratch,
+                            unsigned long long scratch_floats, void* stream) {
   MMSIM_REQUIRE(dh_a && y && mean && rstd && gamma && dy && dgamma && dbeta, "ln_bwd: null operand");
   MMSIM_REQUIRE(H % 4 == 0 && H <= 256 * MAXC, "ln_bwd: H must be a multiple of 4 and <= 2048");
   MMSIM_REQUIRE(dropout_p == 0.f || dt, "ln_bwd: dropout needs a separate dt buffer");
   int rpw = (M + 2047) / 2048;   // ~512 blocks of 4 waves
   if (rpw < 1) rpw = 1;
   const int nblk = (M + 4 * rpw - 1) / (4 * rpw);
+  MMSIM_REQUIRE(scratch && scratch_floats >= (unsigned long long)nblk * 3 * H, "ln_bwd: scratch too small (need blocks*3*H floats)");
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16*)dh_a, (const bf16*)dh_b,
-                     (const bf16*)y, mean, rstd, gamma, (bf16*)dy, (bf16*)dt, dgamma, dbeta, dbias, M, H, rpw,
+                     (const bf16*)y, mean, rstd, gamma, (bf16*)dy, (bf16*)dt, scratch, M, H, rpw,
                      make_drop(dropout_p, seed, stream_id));
+  float* outs[3] = {dgamma, dbeta, dbias};
+  int gy = nblk / 16; if (gy > 8) gy = 8; if (gy < 1) gy = 1;
+  for (int k = 0; k < 3; ++k)
+    if (outs[k])
+      hipLaunchKernelGGL(row_reduce_partials_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream, scratch + (size_t)k * H,
+                         nblk, (size_t)3 * H, H, outs[k]);
   return mmsim_check_launch("ln_bwd");
 }
 

@@ -41,6 +41,19 @@ def _ld(t):
     return t.stride(0) if t.dim() == 2 and t.shape[0] > 1 else t.shape[-1]
 
 
+_SCRATCH = {}
+
+
+def _scratch(device, nfloats):
+    """Reusable fp32 scratch for per-block partial reductions (stream-ordered reuse: one stream per process)."""
+    key = (device.type, device.index)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < nfloats:
+        t = torch.empty(max(nfloats, 1 << 22), dtype=torch.float32, device=device)
+        _SCRATCH[key] = t
+    return t
+
+
 def round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -149,8 +162,9 @@ def ln_bwd(dh_a, dh_b, y, mean, rstd, gamma, dy, dt, dgamma, dbeta, dbias, dropo
         if not x.is_contiguous():
             raise ValueError(f"ln_bwd.{n}: must be contiguous")
     M, H = y.shape
+    scr = _scratch(y.device, 2048 * 3 * H)
     lib.ln_bwd(_p(dh_a), _p(dh_b), _p(y), _p(mean), _p(rstd), _p(gamma), _p(dy), _p(dt), _p(dgamma), _p(dbeta),
-               _p(dbias), M, H, float(dropout_p), seed, stream_id, _stream())
+               _p(dbias), M, H, float(dropout_p), seed, stream_id, _p(scr), scr.numel(), _stream())
 
 
 def colsum(x, out):

@@ -300,7 +300,7 @@ def test_cv_classifier_matches_oracle(name, use_fc):
     loss.backward()
     named = dict(model.named_parameters())
     emb_ref, loss_ref, grads = res[False]
-    emb_emu, _, grads_emu = res[True]
+    emb_emu, loss_emu, grads_emu = res[True]
     d0 = l2err(emb_emu, emb_ref)
     gmax = max(v.norm().item() for v in grads.values())
     keys = [k for k in named if k in grads and named[k].grad is not None and grads[k].norm().item() > 1e-5 * gmax]
@@ -311,7 +311,7 @@ def test_cv_classifier_matches_oracle(name, use_fc):
           f"grad L2 median {ge[len(ge) // 2]:.3f} (envelope {g0[len(g0) // 2]:.3f}) over {len(keys)} tensors")
     assert len(keys) > 50
     assert e < 1.5 * d0 + 0.02
-    assert abs(loss.item() - loss_ref) < 1e-2 * loss_ref
+    assert abs(loss.item() - loss_ref) < 1e-2 * loss_ref + 1.5 * abs(loss_emu - loss_ref)
     assert ge[len(ge) // 2] < 1.5 * g0[len(g0) // 2] + 0.03
     # running statistics follow torch semantics (momentum 0.1, unbiased variance); two forward passes were run
     stats = {}
