@@ -209,8 +209,6 @@ class EfficientNet(nn.Module):
             raise MmsimError("EfficientNet: inputs must be on the GPU; the HIP path has no CPU fallback")
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
             raise ValueError("EfficientNet: expected an NCHW image batch [B,3,H,W] with H, W multiples of 32")
-        if not self.training:
-            raise NotImplementedError("eval-mode (running-statistics) BatchNorm path is not built yet on the HIP side")
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if need_grad:
             return _EffFn.apply(self._anchor, self, x)
@@ -231,6 +229,14 @@ class EfficientNet(nn.Module):
     def _bn_finalize(self, st, name, sums, count):
         fl, s = self._flat, ops._stream()
         o, c = self._bn_off[name], sums.numel() // 2
+        if not self.training:
+            # eval: normalise with the running statistics (nn.BatchNorm2d.eval()); per-channel vectors only
+            rm, rv = self._run[o:o + c], self._run[self._bn_total + o:self._bn_total + o + c]
+            rstd = torch.rsqrt(rv + BN_EPS)
+            scale = fl.view(name + ".weight") * rstd
+            self._bnp(st, name, 0).copy_(rm); self._bnp(st, name, 1).copy_(rstd)
+            self._bnp(st, name, 2).copy_(scale); self._bnp(st, name, 3).copy_(fl.view(name + ".bias") - rm * scale)
+            return
         lib.bn_finalize(sums.data_ptr(), fl.view(name + ".weight").data_ptr(), fl.view(name + ".bias").data_ptr(),
                         self._bnp(st, name, 0).data_ptr(), self._bnp(st, name, 1).data_ptr(),
                         self._bnp(st, name, 2).data_ptr(), self._bnp(st, name, 3).data_ptr(),
@@ -335,7 +341,8 @@ class EfficientNet(nn.Module):
         st.pooled = E(B, a.head, dt=torch.float32)
         lib.pool_bn_act(st.zh.data_ptr(), self._bnp(st, "bn2", 2).data_ptr(), self._bnp(st, "bn2", 3).data_ptr(), None,
                         st.pooled.data_ptr(), B, H * W, a.head, 1, 1.0 / (H * W), s)
-        self._nbt += 1
+        if self.training:
+            self._nbt += 1
         return st
 
     # ------------------------------------------------------------------ backward

@@ -1,0 +1,83 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the gradient exchange (bucket coalescing from tower hooks, gap
+filling, sum semantics, 1/world scale) -- the same code RCCL runs over xGMI on the GPU box."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Tower(torch.nn.Module):
+    """A module with the tower contract: flat_buffers() + grad_ready_hook, parameters as views of the flat buffer."""
+
+    def __init__(self, specs):
+        super().__init__()
+        from multimodalsimilar_amd.flat import FlatBuffer
+        self._flat = FlatBuffer(specs)
+        self._flat.grad = torch.zeros_like(self._flat.master)
+        self.grad_ready_hook = None
+        for i, (n, _) in enumerate(specs):
+            self.register_parameter(f"p{i}", torch.nn.Parameter(self._flat.view(n)))
+
+    def flat_buffers(self):
+        return [self._flat]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodalsimilar_amd.dist import GradientExchange
+    specs = [("a", (37,)), ("b", (64, 9)), ("c", (5, 5)), ("d", (1000,)), ("e", (3,))]
+    root = torch.nn.Module()
+    root.t1, root.t2 = _Tower(specs), _Tower(specs[:3])
+    ex = GradientExchange(root, bucket_bytes=2048)
+    assert ex.world == 2 and abs(ex.grad_scale - 0.5) < 1e-12
+    for step in range(2):          # two steps: state must reset between them
+        for t in (root.t1, root.t2):
+            g = torch.Generator().manual_seed(100 * step + 10 * rank + len(t._flat.names))
+            t._flat.grad.copy_(torch.randn(t._flat.total, generator=g))
+        expect = []
+        for t in (root.t1, root.t2):
+            tot = torch.zeros(t._flat.total)
+            for r in range(world):
+                g = torch.Generator().manual_seed(100 * step + 10 * r + len(t._flat.names))
+                tot += torch.randn(t._flat.total, generator=g)
+            expect.append(tot)
+        f1 = root.t1._flat
+        # the tower reports ranges as its backward finishes them: last tensors first, contiguous ranges merge,
+        # "b" is never reported (finish() must cover the gap), t2 reports nothing at all
+        root.t1.grad_ready_hook(f1, *f1.span("d", "e"))
+        root.t1.grad_ready_hook(f1, *f1.span("c", "c"))
+        root.t1.grad_ready_hook(f1, *f1.span("a", "a"))
+        ex.finish()
+        assert torch.allclose(root.t1._flat.grad, expect[0], atol=1e-6)
+        assert torch.allclose(root.t2._flat.grad, expect[1], atol=1e-6)
+        assert not ex._handles and not ex._pending and not ex._sent
+    if rank == 0:
+        open(out, "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_world2_gloo(tmp_path):
+    out = str(tmp_path / "ok.txt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_single_process_exchange_is_a_noop():
+    from multimodalsimilar_amd.dist import GradientExchange
+    t = _Tower([("a", (8,))])
+    ex = GradientExchange(t)
+    t._flat.grad.fill_(3.0)
+    t.grad_ready_hook(t._flat, 0, 8)
+    ex.finish()
+    assert ex.world == 1 and ex.grad_scale == 1.0 and torch.all(t._flat.grad == 3.0)

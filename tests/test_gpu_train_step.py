@@ -1,0 +1,107 @@
+"""End-to-end training-step parity on the MI355X: loss curves of the HIP path against the CPU oracle's step
+(oracle/step_ref.py: same weights, same batches, torch.optim.AdamW + linear schedules), the reference's literal
+loss path against the fused one, eval / checkpoint plumbing."""
+import io
+import os
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _text_oracle(model, steps):
+    from oracle import bert_ref, step_ref
+    cfg = model.ptm.config
+    shape = bert_ref.BertShape(cfg.vocab_size, cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads,
+                               cfg.intermediate_size, cfg.max_position_embeddings)
+    sd = {k: v.detach().cpu().clone() for k, v in model.ptm.state_dict().items()}
+    return step_ref.TwoTowerOracle(shape, sd, None, None, model.classifier.weight.detach().cpu().clone(), num_steps=steps,
+                                   margin=0.4)
+
+
+def test_text_tower_loss_curve_matches_oracle():
+    from multimodalsimilar_amd import train as T
+    cfg = dict(kind="nlp", text="tiny", seq_len=32, batch=16, classes=64)
+    model = T.build_model(cfg, "cpu", seed=0, dropout=False)
+    steps = 6
+    orc = _text_oracle(model, steps)
+    model.to(DEV)
+    ts = T.TrainStep(model, "nlp", steps)
+    ref, got = [], []
+    for i in range(steps):
+        batch = T.synthetic_batch(cfg, "cpu", seed=50 + i)
+        l, _ = orc.step(batch)
+        ref.append(l.item())
+        l2, pred = ts.step({k: v.to(DEV) for k, v in batch.items()})
+        got.append(l2.item())
+    print("\noracle losses", [round(x, 4) for x in ref], "\nhip    losses", [round(x, 4) for x in got])
+    for a, b in zip(got, ref):
+        assert abs(a - b) < 1.5e-2 * abs(b)
+    # parameters after 6 AdamW steps (lr schedules included) stay together
+    # AdamW's early updates are ~lr*sign(g): an element whose gradient is ~0 may flip, so compare in the mean
+    w = model.classifier.weight.detach().cpu()
+    assert (w - orc.head.detach()).abs().mean() < 2e-3           # head lr warms up to 1e-2 (6 steps of <= 1e-2 each)
+    k = "encoder.layer.1.output.dense.weight"
+    assert (dict(model.ptm.named_parameters())[k].detach().cpu() - orc.text[k].detach()).abs().mean() < 5e-5   # lr 5e-5
+    assert abs(ts.opt_fc.param_groups[0]["lr"] - orc.opt_fc.param_groups[0]["lr"]) < 1e-12
+    assert abs(ts.opt_emb.param_groups[0]["lr"] - orc.opt_emb.param_groups[0]["lr"]) < 1e-12
+
+
+def test_two_tower_step_literal_and_fused_paths_agree_and_track_oracle():
+    from multimodalsimilar_amd import train as T
+    from oracle import bert_ref, step_ref
+    cfg = T.CONFIGS["tiny"]
+    losses = {}
+    for fused in (True, False):
+        model = T.build_model(cfg, "cpu", seed=0, dropout=False)
+        if fused:
+            tshape = bert_ref.BertShape(512, 128, 2, 2, 512, 64)
+            orc = step_ref.TwoTowerOracle(tshape, {k: v.detach().clone() for k, v in model.nlp.ptm.state_dict().items()},
+                                          cfg["image"], {k: v.detach().clone() for k, v in model.cv.state_dict().items()
+                                                         if not k.startswith("classifier")},
+                                          model.classifier.weight.detach().clone(), num_steps=10, margin=0.5)
+        model.cv.to(DEV); model.nlp.to(DEV); model.classifier.to(DEV)
+        ts = T.TrainStep(model, "multimodal", 10, fused_loss=fused)
+        ls = []
+        for i in range(3):
+            batch = T.synthetic_batch(cfg, DEV, seed=70 + i)
+            l, pred = ts.step(batch)
+            ls.append(l.item())
+            assert pred.shape == (cfg["batch"],)
+        losses[fused] = ls
+    ref = [orc.step(T.synthetic_batch(cfg, "cpu", seed=70 + i))[0].item() for i in range(3)]
+    print("\nfused", losses[True], "\nliteral", losses[False], "\noracle", ref)
+    for a, b in zip(losses[True], losses[False]):
+        assert abs(a - b) < 2e-3 * abs(b)          # same kernels underneath, only the loss plumbing differs
+    for a, b in zip(losses[True], ref):
+        assert abs(a - b) < 3e-2 * abs(b)
+
+
+def test_eval_forward_test_and_checkpoint_roundtrip(tmp_path):
+    from multimodalsimilar_amd import train as T
+    cfg = T.CONFIGS["tiny"]
+    model = T.build_model(cfg, DEV, seed=1)
+    ts = T.TrainStep(model, "multimodal", 10)
+    batch = T.synthetic_batch(cfg, DEV, seed=3)
+    ts.step(batch)
+    model.eval()
+    with torch.no_grad():
+        kw = T.model_inputs("multimodal", batch)
+        cos = model(**{**kw, "is_test": True})                 # multimodal_classifier_train.py:215-220
+        emb = model.predict_emb(batch["img_tensor"], batch["input_ids"], batch["token_type_ids"], None, batch["attention_mask"])
+    assert cos.shape == (cfg["batch"], cfg["classes"]) and cos.abs().max() <= 1.0 + 1e-3
+    assert torch.allclose(emb.norm(dim=1), torch.full((cfg["batch"],), 2.0 ** 0.5, device=DEV), atol=1e-3)   # two unit halves
+    with torch.no_grad():
+        cos2 = model(**{**kw, "is_test": True})
+    assert torch.equal(cos, cos2)                              # eval: no dropout, running-stat BatchNorm -> deterministic
+    path = os.path.join(tmp_path, "ckpt.pt")
+    torch.save(model, path)                                    # whole-module pickle (:227)
+    m2 = torch.load(path, weights_only=False)
+    m2.eval()
+    with torch.no_grad():
+        cos3 = m2(**{**kw, "is_test": True})
+    assert torch.allclose(cos3, cos, atol=1e-5)
+    sd = model.state_dict()
+    assert "cv.backbone.blocks.1.0.conv_pw.weight" in sd and "nlp.ptm.encoder.layer.0.attention.self.query.weight" in sd
+    assert "classifier.weight" in sd and "cv.backbone.bn1.running_mean" in sd
