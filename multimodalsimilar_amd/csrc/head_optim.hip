@@ -7,8 +7,12 @@
 
 struct Margin { float s, cos_m, sin_m, th, mm; int easy; };
 
+// Deliberate, documented deviation (DESIGN.md "Numerics"): the reference computes sqrt(1 - cos^2) without a guard
+// (arcface.py:49), which is NaN when |cos| > 1 and has an infinite gradient at |cos| = 1.  With bf16 unit vectors the
+// cosine of a sample aligned with its class row can round to 1 + 2^-8, where the fp32 reference is finite: the radicand
+// is floored at 1e-12 here, which changes nothing wherever the reference itself is finite to fp32 precision.
 __device__ __forceinline__ float margin_fwd(float c, const Margin& m, float* slope) {
-  const float sine = sqrtf(1.0f - c * c);
+  const float sine = sqrtf(fmaxf(1.0f - c * c, 1e-12f));
   const float phi = c * m.cos_m - sine * m.sin_m;
   const bool take = m.easy ? (c > 0.f) : ((c - m.th) > 0.f);
   if (slope) *slope = take ? (m.cos_m + m.sin_m * c / sine) : 1.0f;
