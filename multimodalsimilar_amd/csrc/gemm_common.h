@@ -9,6 +9,7 @@ struct GemmParams {
   float alpha;
   // optional operand transform (1x1 conv after BN + SiLU + squeeze-excite): x -> silu(scale[c] x + shift[c]) * gate[b, c]
   const float* xf_scale; const float* xf_shift; const float* xf_gate; int xf_hw, xf_C;
+  int dbg;   // ablation switches for tools/bench_gemm.py (MMSIM_GEMM_DBG): 1 no DMA, 2 no LDS reads, 4 no MFMA; 0 in production
 };
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_MUL_GELU_GRAD = 2, EPI_ADD = 3, EPI_TANH = 4 };

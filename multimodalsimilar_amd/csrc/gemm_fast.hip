@@ -27,6 +27,30 @@ typedef const void __attribute__((address_space(1))) * glb_void_ptr;
 
 __device__ __forceinline__ int ftr_key(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
+// Transposing LDS read of one 16x32 MFMA operand fragment (two ds_read_b64_tr_b16, rows +0 and +4) as INLINE ASM.
+// With the __builtin form hipcc (ROCm 7.2) cannot prove the read does not alias an in-flight LDS-DMA and inserts
+// s_waitcnt vmcnt(0) in front of every transposed read, which serialises the whole operand pipeline (measured: DMA,
+// LDS reads and MFMAs became purely additive in the NN / TN kernels).  The asm form is invisible to that pass; its
+// completion is covered by the explicit s_waitcnt lgkmcnt(0) each K-step executes before the data is consumed.
+// Plain 16-byte fragment read, also as inline asm: in the software-pipelined kernel the fragments read in step t are
+// consumed in step t+1; a compiler-tracked load would make hipcc wait lgkmcnt(0) at the first MFMA of the next
+// iteration -- AFTER the following slice's reads were issued -- and expose the LDS latency again.
+__device__ __forceinline__ bf8 ds_read_b128_asm(const char* lds_ptr) {
+  const uint32_t a = (uint32_t)(uintptr_t)(lds_s4_ptr)(lds_ptr);
+  bf8 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+
+template <int OFF_HI>
+__device__ __forceinline__ bf8 tr_read_pair_asm(const char* lds_ptr) {
+  const uint32_t a = (uint32_t)(uintptr_t)(lds_s4_ptr)(lds_ptr);
+  s4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "i"(OFF_HI));
+  return __builtin_bit_cast(bf8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 // Issue the LDS-DMA of one operand tile.  NI = wave-instructions per wave (ROWS*128 bytes / 8 waves / 1 KiB).
 // TRANS = false: tile [ROWS][64 k] from X[(r0+row)*ld + k0 + ...];  TRANS = true: tile [64 k][ROWS] from X[(k0+k)*ld + r0 + ...]
 template <bool TRANS, int ROWS>
@@ -62,12 +86,7 @@ __device__ __forceinline__ bf8 ffrag(const char* lds, int rbase, int ks, int lan
     const int k = ks * 32 + 8 * g + q;
     const int cb = rbase >> 4;
     const int off = k * ROWB + ((cb ^ ftr_key(k)) << 5) + p * 8;
-    s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(lds + off));
-    s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(lds + off + 4 * ROWB));
-    s8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return __builtin_bit_cast(bf8, r);
+    return tr_read_pair_asm<4 * ROWB>(lds + off);
   }
 }
 
@@ -199,6 +218,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p) {
       for (int i = 0; i < 4; ++i) af[i] = ffrag<TA, FBM>(la, wm * 64 + i * 16, ks, lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j) bfr[j] = ffrag<!TB_KMAJOR, FBN>(lb, wn * 64 + j * 16, ks, lane);
+      if (TA || !TB_KMAJOR) {          // transposed fragments come from inline asm: wait for them explicitly (rule 18)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -254,17 +277,12 @@ template <bool TRANS>
 __device__ __forceinline__ bf8 gfrag(const char* lds, int rbase, int lane) {
   if (!TRANS) {
     const int row = rbase + (lane & 15), kc = lane >> 4;
-    return *reinterpret_cast<const bf8*>(lds + row * 64 + ((kc ^ ((-(row >> 2)) & 3)) << 4));
+    return ds_read_b128_asm(lds + row * 64 + ((kc ^ ((-(row >> 2)) & 3)) << 4));
   } else {
     const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
     const int k = 8 * g + q;
     const int off = k * 512 + (((rbase >> 4) ^ ftr_key(k)) << 5) + p * 8;
-    s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(lds + off));
-    s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(lds + off + 4 * 512));
-    s8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return __builtin_bit_cast(bf8, r);
+    return tr_read_pair_asm<4 * 512>(lds + off);
   }
 }
 
@@ -293,40 +311,63 @@ __global__ __launch_bounds__(512, 2) void gemm_fast256_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
+  // Software pipeline (per K-slice t):  slice t lives in REGISTERS (fragment set A), slices t+1..t+3 are in the LDS
+  // ring or in flight, and the step reads slice t+1's fragments into set B while the MFMAs of slice t run, so
+  // neither the LDS-read latency nor the DMA latency sits on the MFMA critical path.  Because a slice's slot is
+  // free as soon as its fragments are in registers, the 4-slot ring keeps FOUR slices ahead of the MFMAs.
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
-    if (t < nk) {
+  for (int t = 0; t < 4; ++t)
+    if (t < nk && !(p.dbg & 1)) {
       dma_tile32<TA>(p.A, p.lda, m0, kbeg + t * GBK, smem + t * G_STAGE, wave, lane);
       dma_tile32<!TB_KMAJOR>(p.B, p.ldb, n0, kbeg + t * GBK, smem + t * G_STAGE + G_OP_STAGE, wave, lane);
     }
-  int slot = 0;
-  for (int t = 0; t < nk; ++t) {
-    // 4 LDS-DMA instructions per wave per slice; slices t+1, t+2 may stay in flight
-    const int ahead = nk - 1 - t;
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  bf8 afA[8], bfA[4], afB[8], bfB[4];
+  {
+    const int ahead = min(nk - 1, 3);                    // slices issued after slice 0
+    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + 3 < nk) {
-      const int ns = (slot + 3) & 3;
-      dma_tile32<TA>(p.A, p.lda, m0, kbeg + (t + 3) * GBK, smem + ns * G_STAGE, wave, lane);
-      dma_tile32<!TB_KMAJOR>(p.B, p.ldb, n0, kbeg + (t + 3) * GBK, smem + ns * G_STAGE + G_OP_STAGE, wave, lane);
-    }
-    const char* la = smem + slot * G_STAGE;
-    const char* lb = la + G_OP_STAGE;
-    bf8 af[8], bfr[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bfr[j] = gfrag<!TB_KMAJOR>(lb, wn * 64 + j * 16, lane);
+    for (int j = 0; j < 4; ++j) bfA[j] = gfrag<!TB_KMAJOR>(smem + G_OP_STAGE, wn * 64 + j * 16, lane);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) af[i] = gfrag<TA>(la, wm * 128 + i * 16, lane);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    slot = (slot + 1) & 3;
+    for (int i = 0; i < 8; ++i) afA[i] = gfrag<TA>(smem, wm * 128 + i * 16, lane);
   }
+  // one pipeline step: consume (af0, bf0) = slice t, fill (af1, bf1) with slice t+1, refill the ring with slice t+4
+#define GEMM256_STEP(af0, bf0, af1, bf1, T)                                                                         \
+  {                                                                                                                 \
+    const int t_ = (T);                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* slice t's fragments (asm + compiler LDS reads) landed */ \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    if (t_ + 1 < nk) {                                                                                              \
+      const int ahead = min(nk - 2 - t_, 2);           /* slices issued after slice t+1 */                        \
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                   \
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                              \
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                              \
+      __builtin_amdgcn_s_barrier();                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      if (t_ + 4 < nk && !(p.dbg & 1)) {                                                                            \
+        char* ns = smem + (t_ & 3) * G_STAGE;          /* slot of slice t: its fragments are in registers */        \
+        dma_tile32<TA>(p.A, p.lda, m0, kbeg + (t_ + 4) * GBK, ns, wave, lane);                                      \
+        dma_tile32<!TB_KMAJOR>(p.B, p.ldb, n0, kbeg + (t_ + 4) * GBK, ns + G_OP_STAGE, wave, lane);                 \
+      }                                                                                                             \
+      const char* la = smem + ((t_ + 1) & 3) * G_STAGE;                                                             \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) bf1[j] = gfrag<!TB_KMAJOR>(la + G_OP_STAGE, wn * 64 + j * 16, lane); \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) af1[i] = gfrag<TA>(la, wm * 128 + i * 16, lane);               \
+    }                                                                                                               \
+    if (!(p.dbg & 4)) {                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j], af0[i], acc[i][j], 0, 0, 0);                  \
+    }                                                                                                               \
+  }
+  for (int t = 0; t < nk; t += 2) {
+    GEMM256_STEP(afA, bfA, afB, bfB, t)
+    if (t + 1 < nk) GEMM256_STEP(afB, bfB, afA, bfA, t + 1)
+  }
+#undef GEMM256_STEP
   const bool fs = split == 0;
   float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
 #pragma unroll

@@ -1,0 +1,26 @@
+"""Ablation of the 256x256x32 GEMM main loop (GPU box): MMSIM_GEMM_DBG bits 1 = no DMA, 2 = no LDS reads, 4 = no MFMA."""
+import os, subprocess, sys
+code = r'''
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from multimodalsimilar_amd import ops
+M=32768
+for name,N,K,lay in (("ffn1-NT",4096,1024,"nt"),("ffn2-NT",1024,4096,"nt"),("ffn1-NN",1024,4096,"nn")):
+    if lay=="nt":
+        a=torch.randn(M,K,device="cuda").bfloat16(); b=(torch.randn(N,K,device="cuda")*0.05).bfloat16(); kw={}
+    else:
+        a=torch.randn(M,K,device="cuda").bfloat16(); b=(torch.randn(K,N,device="cuda")*0.05).bfloat16(); kw=dict(b_kmajor=False)
+    c=torch.empty(M,N,dtype=torch.bfloat16,device="cuda")
+    f=lambda: ops.gemm(a,b,c,**kw)
+    f(); torch.cuda.synchronize()
+    e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): f()
+    e1.record(); torch.cuda.synchronize()
+    t=e0.elapsed_time(e1)/10
+    print(f"  {name}: {t*1e3:8.1f} us  ({2.0*M*N*K/t/1e9:7.1f} TF-equivalent)")
+'''
+for dbg, label in ((0, "full"), (1, "no DMA"), (2, "no LDS reads"), (4, "no MFMA"), (3, "MFMA only"), (6, "DMA only"), (5, "LDS reads only")):
+    print(f"dbg={dbg} [{label}]", flush=True)
+    env = dict(os.environ, MMSIM_GEMM_DBG=str(dbg))
+    subprocess.run([sys.executable, "-c", code], env=env)
