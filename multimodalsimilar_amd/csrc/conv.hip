@@ -188,74 +188,100 @@ __global__ __launch_bounds__(256) void pool_bn_act_kernel(const bf16* __restrict
 }
 
 // ------------------------------------------------------------------ squeeze-excite MLP
-// s [B,C] -> hr = Wr s + br (pre-activation, saved) -> gate = sigmoid(We silu(hr) + be)
-__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* s, const float* Wr, const float* br, const float* We,
-                                                         const float* be, float* hr_out, float* gate, int C, int RD) {
-  extern __shared__ float sm[];
-  float* sv = sm;            // [C]
-  float* hv = sm + C;        // [RD]
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < C; c += 256) sv[c] = s[(size_t)b * C + c];
-  __syncthreads();
-  for (int j = wv; j < RD; j += 4) {
+// Both 1x1 convs of the SE branch are tiny (B x C x RD MACs) and latency-bound if one block walks an image serially.
+// They are expressed with two generic, well-parallel kernels over weights stored [R][C] (C contiguous):
+//   se_rowdot : out[b, r] = post( sum_c W[r][c] * pre(x[b, c]) + bias[r] )       (reduction over C: wave per (b, r))
+//   se_colmix : out[b, c] = post( sum_r W[r][c] * pre(y[b, r]) + bias[c] )       (reduction over R: thread per (b, c))
+// conv_reduce.weight is [RD][C] already; conv_expand.weight ([C][RD]) is transposed once per step into [RD][C].
+enum { SE_PRE_NONE = 0, SE_PRE_SILU = 1, SE_PRE_DSIGMOID = 2 };     // DSIGMOID: x * g * (1 - g) with g = aux[b, c]
+enum { SE_POST_NONE = 0, SE_POST_SIGMOID = 1, SE_POST_MUL_DSILU = 2 };   // MUL_DSILU: out * silu'(aux2[b, r])
+
+__global__ __launch_bounds__(256) void se_rowdot_kernel(const float* __restrict__ W, const float* __restrict__ x,
+                                                        const float* __restrict__ aux, const float* __restrict__ bias,
+                                                        const float* __restrict__ aux2, float* out, int B, int C, int R,
+                                                        int pre, int post) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = blockIdx.x;
+  const float* w = W + (size_t)r * C;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {                       // 8 images per block, 2 per wave
+    const int b = blockIdx.y * 8 + wv * 2 + k;
+    if (b >= B) break;
     float a = 0.f;
-    for (int c = lane; c < C; c += 64) a += Wr[(size_t)j * C + c] * sv[c];
-    a = wave_sum(a) + br[j];
-    if (lane == 0) { hr_out[(size_t)b * RD + j] = a; hv[j] = silu_f(a); }
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float a = be[c];
-    for (int j = 0; j < RD; ++j) a += We[(size_t)c * RD + j] * hv[j];
-    gate[(size_t)b * C + c] = sigmoid_f(a);
+    for (int c = lane * 4; c < C; c += 256) {          // C is a multiple of 8
+      const float4 ww = *reinterpret_cast<const float4*>(w + c);
+      float4 xx = *reinterpret_cast<const float4*>(x + (size_t)b * C + c);
+      if (pre == SE_PRE_DSIGMOID) {
+        const float4 g = *reinterpret_cast<const float4*>(aux + (size_t)b * C + c);
+        xx.x *= g.x * (1.f - g.x); xx.y *= g.y * (1.f - g.y); xx.z *= g.z * (1.f - g.z); xx.w *= g.w * (1.f - g.w);
+      }
+      a += ww.x * xx.x + ww.y * xx.y + ww.z * xx.z + ww.w * xx.w;
+    }
+    a = wave_sum(a);
+    if (lane == 0) {
+      if (bias) a += bias[r];
+      if (post == SE_POST_MUL_DSILU) a *= silu_grad_f(aux2[(size_t)b * R + r]);
+      out[(size_t)b * R + r] = a;
+    }
   }
 }
 
-// dgate [B,C] -> dpe = dgate*g*(1-g) (saved) ; dr = (We^T dpe) * silu'(hr) (saved) ; ds = Wr^T dr
-__global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* dgate, const float* gate, const float* hr,
-                                                         const float* Wr, const float* We, float* dpe_out, float* dr_out,
-                                                         float* ds, int C, int RD) {
-  extern __shared__ float sm[];
-  float* dv = sm;            // dpe [C]
-  float* rv = sm + C;        // dr [RD]
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < C; c += 256) {
+__global__ __launch_bounds__(256) void se_colmix_kernel(const float* __restrict__ W, const float* __restrict__ y,
+                                                        const float* __restrict__ bias, float* out, int B, int C, int R,
+                                                        int pre, int post) {
+  __shared__ float ys[4][128];                        // R <= 128
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int b = blockIdx.y * 4 + wv;
+  if (b < B)
+    for (int r = lane; r < R; r += 64) {
+      float v = y[(size_t)b * R + r];
+      ys[wv][r] = pre == SE_PRE_SILU ? silu_f(v) : v;
+    }
+  __syncthreads();
+  if (b >= B || c >= C) return;
+  float a0 = bias ? bias[c] : 0.f, a1 = 0.f;
+  int r = 0;
+  for (; r + 1 < R; r += 2) { a0 += W[(size_t)r * C + c] * ys[wv][r]; a1 += W[(size_t)(r + 1) * C + c] * ys[wv][r + 1]; }
+  if (r < R) a0 += W[(size_t)r * C + c] * ys[wv][r];
+  float a = a0 + a1;
+  if (post == SE_POST_SIGMOID) a = sigmoid_f(a);
+  out[(size_t)b * C + c] = a;
+}
+
+// [C][R] <-> [R][C] (weights: overwrite; gradients: accumulate back)
+__global__ void se_transpose_kernel(const float* in, float* out, int rows, int cols, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int r = i / cols, c = i % cols;
+  if (accumulate) out[(size_t)c * rows + r] += in[i];
+  else out[(size_t)c * rows + r] = in[i];
+}
+
+// weight gradients, thread per (r, c) with c fastest (coalesced), reductions over the batch:
+//   dWr[r][c] += sum_b dr[b,r] * s[b,c]      dWeT[r][c] = sum_b dpe[b,c] * silu(hr[b,r]),  dpe = dgate*g*(1-g)
+//   dbr[r] += sum_b dr[b,r]                  dbe[c] += sum_b dpe[b,c]
+__global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                       const float* __restrict__ dr, const float* __restrict__ hr,
+                                                       const float* __restrict__ s, float* dWr, float* dbr, float* dWeT, float* dbe,
+                                                       int B, int C, int R) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= C * R) return;
+  const int r = idx / C, c = idx % C;
+  float ae = 0.f, ar = 0.f, ab = 0.f, abr = 0.f;
+#pragma unroll 4
+  for (int b = 0; b < B; ++b) {
     const float g = gate[(size_t)b * C + c];
     const float d = dgate[(size_t)b * C + c] * g * (1.f - g);
-    dv[c] = d; dpe_out[(size_t)b * C + c] = d;
+    const float rr = dr[(size_t)b * R + r];
+    ae += d * silu_f(hr[(size_t)b * R + r]);
+    ar += rr * s[(size_t)b * C + c];
+    ab += d; abr += rr;
   }
-  __syncthreads();
-  for (int j = wv; j < RD; j += 4) {
-    float a = 0.f;
-    for (int c = lane; c < C; c += 64) a += We[(size_t)c * RD + j] * dv[c];
-    a = wave_sum(a) * silu_grad_f(hr[(size_t)b * RD + j]);
-    if (lane == 0) { rv[j] = a; dr_out[(size_t)b * RD + j] = a; }
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float a = 0.f;
-    for (int j = 0; j < RD; ++j) a += Wr[(size_t)j * C + c] * rv[j];
-    ds[(size_t)b * C + c] = a;
-  }
-}
-
-// weight gradients of the two SE convs (reductions over the batch); thread per (c, j)
-__global__ __launch_bounds__(256) void se_wgrad_kernel(const float* dpe, const float* dr, const float* hr, const float* s,
-                                                       float* dWr, float* dbr, float* dWe, float* dbe, int B, int C, int RD) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= C * RD) return;
-  const int c = idx / RD, j = idx % RD;
-  float ae = 0.f, ar = 0.f, ab = 0.f, abr = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float d = dpe[(size_t)b * C + c], r = dr[(size_t)b * RD + j];
-    ae += d * silu_f(hr[(size_t)b * RD + j]);
-    ar += r * s[(size_t)b * C + c];
-    ab += d; abr += r;
-  }
-  dWe[(size_t)c * RD + j] += ae;
-  dWr[(size_t)j * C + c] += ar;
-  if (j == 0) dbe[c] += ab;
-  if (c == 0) dbr[j] += abr;
+  dWeT[idx] = ae;
+  dWr[idx] += ar;
+  if (r == 0) dbe[c] += ab;
+  if (c == 0) dbr[r] += abr;
 }
 
 // ------------------------------------------------------------------ BN (+SiLU, +SE gate) backward
@@ -540,17 +566,47 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16* __re
       if (hi < 0 || hi >= g.Hi) continue;
       const bf16* arow = a + (((size_t)b * g.Hi + hi) * g.Wi) * g.C + c0;
       const bf16* drow = dz + (((size_t)b * g.Ho + ho) * g.Wo) * g.C + c0;
-      for (int wo = 0; wo < g.Wo; ++wo) {
-        float d[8];
-        unpack8(*reinterpret_cast<const uint4*>(drow + (size_t)wo * g.C), d);
+      if constexpr (S == 1) {
+        // sliding window over the input row: one new input chunk + one dz chunk per output pixel (instead of K + 1)
+        float win[K][8];
 #pragma unroll
-        for (int kw = 0; kw < K; ++kw) {
-          const int wi = wo * S - PAD + kw;
-          if (wi < 0 || wi >= g.Wi) continue;
-          float x[8];
-          unpack8(*reinterpret_cast<const uint4*>(arow + (size_t)wi * g.C), x);
+        for (int x = 0; x < K - 1; ++x) {
+          const int wi = x - PAD;
+          if (wi >= 0 && wi < g.Wi) unpack8(*reinterpret_cast<const uint4*>(arow + (size_t)wi * g.C), win[x + 1]);
+          else
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[kw * 8 + e] += d[e] * x[e];
+            for (int e = 0; e < 8; ++e) win[x + 1][e] = 0.f;
+        }
+        for (int wo = 0; wo < g.Wo; ++wo) {
+#pragma unroll
+          for (int x = 0; x < K - 1; ++x)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) win[x][e] = win[x + 1][e];
+          const int wi = wo + K - 1 - PAD;
+          if (wi < g.Wi) unpack8(*reinterpret_cast<const uint4*>(arow + (size_t)wi * g.C), win[K - 1]);
+          else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) win[K - 1][e] = 0.f;
+          float d[8];
+          unpack8(*reinterpret_cast<const uint4*>(drow + (size_t)wo * g.C), d);
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[kw * 8 + e] += d[e] * win[kw][e];
+        }
+      } else {
+        for (int wo = 0; wo < g.Wo; ++wo) {
+          float d[8];
+          unpack8(*reinterpret_cast<const uint4*>(drow + (size_t)wo * g.C), d);
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            const int wi = wo * S - PAD + kw;
+            if (wi < 0 || wi >= g.Wi) continue;
+            float x[8];
+            unpack8(*reinterpret_cast<const uint4*>(arow + (size_t)wi * g.C), x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[kw * 8 + e] += d[e] * x[e];
+          }
         }
       }
     }
@@ -755,23 +811,37 @@ extern "C" int mmsim_pool_bn_act(const void* z, const float* scale, const float*
   return mmsim_check_launch("pool_bn_act");
 }
 
+/* weT: scratch [RD][C] receiving conv_expand.weight transposed (reused by the backward of the same step) */
 extern "C" int mmsim_se_mlp_fwd(const float* s, const float* w_reduce, const float* b_reduce, const float* w_expand,
-                                const float* b_expand, float* hr, float* gate, int B, int C, int RD, void* stream) {
-  MMSIM_REQUIRE(s && w_reduce && b_reduce && w_expand && b_expand && hr && gate && B > 0 && C > 0 && RD > 0, "se_mlp_fwd: bad arguments");
-  hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(B), dim3(256), (size_t)(C + RD) * 4, (hipStream_t)stream, s, w_reduce, b_reduce,
-                     w_expand, b_expand, hr, gate, C, RD);
+                                const float* b_expand, float* weT, float* hr, float* gate, int B, int C, int RD, void* stream) {
+  MMSIM_REQUIRE(s && w_reduce && b_reduce && w_expand && b_expand && weT && hr && gate && B > 0 && C > 0 && RD > 0, "se_mlp_fwd: bad arguments");
+  MMSIM_REQUIRE(C % 8 == 0 && RD <= 128, "se_mlp_fwd: C must be a multiple of 8 and RD <= 128");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(se_transpose_kernel, dim3((C * RD + 255) / 256), dim3(256), 0, st, w_expand, weT, C, RD, 0);
+  hipLaunchKernelGGL(se_rowdot_kernel, dim3(RD, (B + 7) / 8), dim3(256), 0, st, w_reduce, s, (const float*)nullptr, b_reduce,
+                     (const float*)nullptr, hr, B, C, RD, SE_PRE_NONE, SE_POST_NONE);
+  hipLaunchKernelGGL(se_colmix_kernel, dim3((C + 63) / 64, (B + 3) / 4), dim3(256), 0, st, weT, hr, b_expand, gate, B, C, RD, SE_PRE_SILU,
+                     SE_POST_SIGMOID);
   return mmsim_check_launch("se_mlp_fwd");
 }
 
+/* dr [B,RD], ds [B,C]: outputs; dweT: scratch [RD][C].  Weight / bias gradients are accumulated. */
 extern "C" int mmsim_se_mlp_bwd(const float* dgate, const float* gate, const float* hr, const float* s, const float* w_reduce,
-                                const float* w_expand, float* dpe, float* dr, float* ds, float* dw_reduce, float* db_reduce,
+                                const float* weT, float* dr, float* ds, float* dweT, float* dw_reduce, float* db_reduce,
                                 float* dw_expand, float* db_expand, int B, int C, int RD, void* stream) {
-  MMSIM_REQUIRE(dgate && gate && hr && s && w_reduce && w_expand && dpe && dr && ds && dw_reduce && db_reduce && dw_expand && db_expand,
+  MMSIM_REQUIRE(dgate && gate && hr && s && w_reduce && weT && dr && ds && dweT && dw_reduce && db_reduce && dw_expand && db_expand,
                 "se_mlp_bwd: null operand");
-  hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B), dim3(256), (size_t)(C + RD) * 4, (hipStream_t)stream, dgate, gate, hr, w_reduce,
-                     w_expand, dpe, dr, ds, C, RD);
-  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * RD + 255) / 256), dim3(256), 0, (hipStream_t)stream, dpe, dr, hr, s, dw_reduce,
-                     db_reduce, dw_expand, db_expand, B, C, RD);
+  MMSIM_REQUIRE(C % 8 == 0 && RD <= 128, "se_mlp_bwd: C must be a multiple of 8 and RD <= 128");
+  hipStream_t st = (hipStream_t)stream;
+  // dr[b,j] = (sum_c We[c,j] dpe[b,c]) * silu'(hr[b,j]),  dpe = dgate * g * (1 - g)
+  hipLaunchKernelGGL(se_rowdot_kernel, dim3(RD, (B + 7) / 8), dim3(256), 0, st, weT, dgate, gate, (const float*)nullptr, hr, dr, B, C, RD,
+                     SE_PRE_DSIGMOID, SE_POST_MUL_DSILU);
+  // ds[b,c] = sum_j Wr[j,c] dr[b,j]
+  hipLaunchKernelGGL(se_colmix_kernel, dim3((C + 63) / 64, (B + 3) / 4), dim3(256), 0, st, w_reduce, dr, (const float*)nullptr, ds, B, C, RD,
+                     SE_PRE_NONE, SE_POST_NONE);
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * RD + 255) / 256), dim3(256), 0, st, dgate, gate, dr, hr, s, dw_reduce, db_reduce, dweT,
+                     db_expand, B, C, RD);
+  hipLaunchKernelGGL(se_transpose_kernel, dim3((C * RD + 255) / 256), dim3(256), 0, st, dweT, dw_expand, RD, C, 1);
   return mmsim_check_launch("se_mlp_bwd");
 }
 
