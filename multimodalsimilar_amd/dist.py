@@ -36,8 +36,14 @@ class GradientExchange:
     def _launch(self, flat, start, end):
         if self.world == 1 or end <= start:
             return
-        h = dist.all_reduce(flat.grad[start:end], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self._handles.append(h)
+        t = flat.grad[start:end]
+        if t.is_cuda and dist.get_backend(self.pg) == "gloo":
+            # rehearsal mode (several ranks sharing one GPU, where RCCL refuses duplicate devices): stage through the host
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+            t.copy_(h)
+        else:
+            self._handles.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         self._sent.setdefault(id(flat), []).append((start, end))
 
     def _on_ready(self, flat, start, end):

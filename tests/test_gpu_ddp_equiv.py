@@ -1,0 +1,64 @@
+"""Data-parallel equivalence on the GPU box: two ranks (two processes sharing the one GPU, gloo rendezvous on
+127.0.0.1 -- RCCL refuses duplicate devices, the exchange code path is otherwise the same) each take half of a batch;
+after one step their parameters must equal a single process stepping on the whole batch: the update is the gradient of
+the GLOBAL-batch mean loss (reference semantics, nlp_classifier_train_daodian_v2_dist.py:139-144)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+CFG = dict(kind="nlp", text="tiny", seq_len=32, batch=16, classes=64)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from multimodalsimilar_amd import train as T
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = T.build_model(CFG, "cuda", seed=0, dropout=False)
+    ts = T.TrainStep(model, "nlp", 10)
+    assert ts.exchange is not None and ts.exchange.world == 2
+    full = T.synthetic_batch(CFG, "cuda", seed=5)
+    half = {k: v[rank * 8:(rank + 1) * 8] for k, v in full.items()}
+    loss, _ = ts.step(half)
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process_on_the_whole_batch(tmp_path):
+    from multimodalsimilar_amd import train as T
+    out = str(tmp_path / "ddp.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    ddp = torch.load(out)
+    model = T.build_model(CFG, "cuda", seed=0, dropout=False)
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ts = T.TrainStep(model, "nlp", 10)
+    ts.step(T.synthetic_batch(CFG, "cuda", seed=5))
+    torch.cuda.synchronize()
+    single = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    checked = 0
+    for k in ("classifier.weight", "ptm.encoder.layer.1.output.dense.weight", "ptm.encoder.layer.0.attention.self.query.weight",
+              "ptm.embeddings.word_embeddings.weight", "ptm.pooler.dense.bias"):
+        upd = (single[k] - sd0[k]).abs().mean().item()
+        diff = (single[k] - ddp[k]).abs().mean().item()
+        assert upd > 0, k                                  # the step moved the parameter ...
+        assert diff < 0.05 * upd + 1e-9, (k, diff, upd)     # ... and both ways of running it moved it the same way
+        checked += 1
+    assert checked == 5
