@@ -53,7 +53,7 @@ def _goes_to_fast256_nt(a, b, c, trans_a, b_kmajor, kw):
     if trans_a or not b_kmajor or kw.get("split_k", 1) != 1:
         return False
     M, N, K = c.shape[0], c.shape[1], a.shape[1]
-    return M % 256 == 0 and N % 256 == 0 and K % 32 == 0 and (M // 256) * (N // 256) >= 128
+    return M % 256 == 0 and N % 256 == 0 and K % 32 == 0 and (M // 256) * (N // 256) >= 128 and c.stride(0) % 4 == 0
 
 
 class GemmTimer:
@@ -209,7 +209,7 @@ def main():
             "metric": "image-text pairs/sec/step (two-tower+ArcFace, bs=256)", "value": pairs / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.config}: " + {"multimodal": "roberta-wwm-ext-large + efficientnet_b4 two-tower + ArcFace",
+            "config": {"workload": f"{args.config}: " + {"multimodal": f"roberta-wwm-ext-{cfg.get('text')} + {cfg.get('image')} two-tower + ArcFace",
                                                         "nlp": "text tower + ArcFace", "cv": "image tower + ArcFace"}[cfg["kind"]],
                        "per_gpu_batch": cfg["batch"], "global_batch": world * cfg["batch"], "seq_len": cfg.get("seq_len"),
                        "image": cfg.get("res"), "classes": cfg["classes"], "parallelism": f"dp{world}",
@@ -218,7 +218,7 @@ def main():
                        "step_mfma_frac": (fpp * cfg["batch"] / (ms * 1e-3) / 1e12) / MFMA_BF16_PEAK_TFLOPS,
                        "final_loss": lossv},
             "roofline": None if g is None else {
-                "bound": "mfma", "kernel": "gemm_fast256_kernel<false,true> (Y = X W^T: 256x256x32 tiles, LDS-DMA ring, bf16 MFMA 16x16x32, fp32 accumulate)",
+                "bound": "mfma", "kernel": "gemm_fast256_kernel<false,true,256> (Y = X W^T: 256x256x32 tiles, LDS-DMA ring, bf16 MFMA 16x16x32, fp32 accumulate)",
                 "achieved": g["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": None, "launches": g["launches"], "avg_launch_us": g["avg_us"]},
         }

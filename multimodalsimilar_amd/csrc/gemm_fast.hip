@@ -250,22 +250,22 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p) {
 #define GBM 256
 #define GBN 256
 #define GBK 32
-#define G_OP_STAGE (256 * 64)              // 16 KiB per operand per slot
-#define G_STAGE (2 * G_OP_STAGE)
 #define G_SLOTS 4
 
-template <bool TRANS>
+template <bool TRANS, int ROWS>      // ROWS = 256 or 128 rows (k-major) / columns (transposed) of the operand tile
 __device__ __forceinline__ void dma_tile32(const bf16* __restrict__ X, int ld, int r0, int k0, char* lds, int wave, int lane) {
+  constexpr int NI = ROWS / 128;        // 1-KiB wave-instructions per wave: the tile is ROWS*64 bytes
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int blk = wave * 2 + i;                        // 16 blocks of 1 KiB
+  for (int i = 0; i < NI; ++i) {
+    const int blk = wave * NI + i;
     const bf16* src;
     if (!TRANS) {
       const int row = blk * 16 + (lane >> 2), pos = lane & 3;
       const int c = pos ^ ((-(row >> 2)) & 3);
       src = X + (size_t)(r0 + row) * ld + k0 + c * 8;
     } else {
-      const int k = blk * 2 + (lane >> 5), pc = lane & 31;          // 512-B k-rows, 32 chunks each
+      constexpr int CPR = ROWS / 8;      // 16-B chunks per k-row (32 or 16); a 1-KiB block holds 64 / CPR k-rows
+      const int k = blk * (64 / CPR) + lane / CPR, pc = lane % CPR;
       const int c = (((pc >> 1) ^ ftr_key(k)) << 1) | (pc & 1);
       src = X + (size_t)(k0 + k) * ld + r0 + c * 8;
     }
@@ -273,7 +273,7 @@ __device__ __forceinline__ void dma_tile32(const bf16* __restrict__ X, int ld, i
   }
 }
 
-template <bool TRANS>
+template <bool TRANS, int ROWS>
 __device__ __forceinline__ bf8 gfrag(const char* lds, int rbase, int lane) {
   if (!TRANS) {
     const int row = rbase + (lane & 15), kc = lane >> 4;
@@ -281,17 +281,21 @@ __device__ __forceinline__ bf8 gfrag(const char* lds, int rbase, int lane) {
   } else {
     const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
     const int k = 8 * g + q;
-    const int off = k * 512 + (((rbase >> 4) ^ ftr_key(k)) << 5) + p * 8;
-    return tr_read_pair_asm<4 * 512>(lds + off);
+    const int off = k * (ROWS * 2) + (((rbase >> 4) ^ ftr_key(k)) << 5) + p * 8;
+    return tr_read_pair_asm<4 * ROWS * 2>(lds + off);
   }
 }
 
-template <bool TA, bool TB_KMAJOR>
+template <bool TA, bool TB_KMAJOR, int BN>     // BN = 256: 2 x 4 waves of 128 x 64;  BN = 128: 4 x 2 waves of 64 x 64
 __global__ __launch_bounds__(512, 2) void gemm_fast256_kernel(GemmParams p) {
+  constexpr int MT = BN == 256 ? 8 : 4;                  // 16-row MFMA tiles per wave along M
+  constexpr int WROWS = MT * 16;
+  constexpr int A_BYTES = GBM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
+  constexpr int LPS = 2 + BN / 128;                      // LDS-DMA instructions per wave per K-slice
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;               // 2 x 4 waves, 128 x 64 each
+  const int wm = BN == 256 ? (wave >> 2) : (wave >> 1), wn = BN == 256 ? (wave & 3) : (wave & 1);
 
   const int ntiles = p.tiles_m * p.tiles_n;
   const int nwg = ntiles * p.splits;
@@ -300,14 +304,14 @@ __global__ __launch_bounds__(512, 2) void gemm_fast256_kernel(GemmParams p) {
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   const int split = wg / ntiles, tile = wg - split * ntiles;
   const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-  const int m0 = tm * GBM, n0 = tn * GBN;
+  const int m0 = tm * GBM, n0 = tn * BN;
   const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nk = (kend - kbeg) / GBK;
 
-  f4 acc[8][4];
+  f4 acc[MT][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
@@ -318,22 +322,22 @@ __global__ __launch_bounds__(512, 2) void gemm_fast256_kernel(GemmParams p) {
 #pragma unroll
   for (int t = 0; t < 4; ++t)
     if (t < nk && !(p.dbg & 1)) {
-      dma_tile32<TA>(p.A, p.lda, m0, kbeg + t * GBK, smem + t * G_STAGE, wave, lane);
-      dma_tile32<!TB_KMAJOR>(p.B, p.ldb, n0, kbeg + t * GBK, smem + t * G_STAGE + G_OP_STAGE, wave, lane);
+      dma_tile32<TA, GBM>(p.A, p.lda, m0, kbeg + t * GBK, smem + t * STAGE, wave, lane);
+      dma_tile32<!TB_KMAJOR, BN>(p.B, p.ldb, n0, kbeg + t * GBK, smem + t * STAGE + A_BYTES, wave, lane);
     }
-  bf8 afA[8], bfA[4], afB[8], bfB[4];
+  bf8 afA[MT], bfA[4], afB[MT], bfB[4];
   {
     const int ahead = min(nk - 1, 3);                    // slices issued after slice 0
-    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
+    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bfA[j] = gfrag<!TB_KMAJOR>(smem + G_OP_STAGE, wn * 64 + j * 16, lane);
+    for (int j = 0; j < 4; ++j) bfA[j] = gfrag<!TB_KMAJOR, BN>(smem + A_BYTES, wn * 64 + j * 16, lane);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) afA[i] = gfrag<TA>(smem, wm * 128 + i * 16, lane);
+    for (int i = 0; i < MT; ++i) afA[i] = gfrag<TA, GBM>(smem, wm * WROWS + i * 16, lane);
   }
   // one pipeline step: consume (af0, bf0) = slice t, fill (af1, bf1) with slice t+1, refill the ring with slice t+4
 #define GEMM256_STEP(af0, bf0, af1, bf1, T)                                                                         \
@@ -343,22 +347,22 @@ __global__ __launch_bounds__(512, 2) void gemm_fast256_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);                                                                              \
     if (t_ + 1 < nk) {                                                                                              \
       const int ahead = min(nk - 2 - t_, 2);           /* slices issued after slice t+1 */                        \
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                   \
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                              \
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                              \
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");                                \
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");                               \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
       __builtin_amdgcn_s_barrier();                                                                                 \
       __builtin_amdgcn_sched_barrier(0);                                                                            \
       if (t_ + 4 < nk && !(p.dbg & 1)) {                                                                            \
-        char* ns = smem + (t_ & 3) * G_STAGE;          /* slot of slice t: its fragments are in registers */        \
-        dma_tile32<TA>(p.A, p.lda, m0, kbeg + (t_ + 4) * GBK, ns, wave, lane);                                      \
-        dma_tile32<!TB_KMAJOR>(p.B, p.ldb, n0, kbeg + (t_ + 4) * GBK, ns + G_OP_STAGE, wave, lane);                 \
+        char* ns = smem + (t_ & 3) * STAGE;            /* slot of slice t: its fragments are in registers */        \
+        dma_tile32<TA, GBM>(p.A, p.lda, m0, kbeg + (t_ + 4) * GBK, ns, wave, lane);                                 \
+        dma_tile32<!TB_KMAJOR, BN>(p.B, p.ldb, n0, kbeg + (t_ + 4) * GBK, ns + A_BYTES, wave, lane);                \
       }                                                                                                             \
-      const char* la = smem + ((t_ + 1) & 3) * G_STAGE;                                                             \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) bf1[j] = gfrag<!TB_KMAJOR>(la + G_OP_STAGE, wn * 64 + j * 16, lane); \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i) af1[i] = gfrag<TA>(la, wm * 128 + i * 16, lane);               \
+      const char* la = smem + ((t_ + 1) & 3) * STAGE;                                                               \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) bf1[j] = gfrag<!TB_KMAJOR, BN>(la + A_BYTES, wn * 64 + j * 16, lane); \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) af1[i] = gfrag<TA, GBM>(la, wm * WROWS + i * 16, lane);        \
     }                                                                                                               \
     if (!(p.dbg & 4)) {                                                                                             \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                 \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j], af0[i], acc[i][j], 0, 0, 0);                  \
     }                                                                                                               \
@@ -371,10 +375,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fast256_kernel(GemmParams p) {
   const bool fs = split == 0;
   float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < MT / 4; ++half) {
     __syncthreads();          // ring (first pass) / previous staging pass fully consumed
     f4 (&a4)[4][4] = *reinterpret_cast<f4 (*)[4][4]>(&acc[half * 4][0]);
-    const int row0 = m0 + wm * 128 + half * 64, col0 = n0 + wn * 64;
+    const int row0 = m0 + wm * WROWS + half * 64, col0 = n0 + wn * 64;
     if (!p.c_f32) fast_epilogue_epi<0>(p, a4, row0, col0, lane, fs, stg);
     else if (p.atomic) fast_epilogue<EPI_NONE, 3>(p, a4, row0, col0, lane, fs, stg);
     else if (p.accum) fast_epilogue<EPI_NONE, 2>(p, a4, row0, col0, lane, fs, stg);
@@ -383,11 +387,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fast256_kernel(GemmParams p) {
   }
 }
 
-static bool fast256_eligible(const GemmParams& p, int splits) {
-  if (p.M % GBM || p.N % GBN || p.K % GBK || p.k_per_split % GBK) return false;
-  return (p.M / GBM) * (p.N / GBN) * splits >= 128;        // enough blocks to fill the chip
+static bool pipe_eligible(const GemmParams& p, int splits, int bn) {
+  if (p.M % GBM || p.N % bn || p.K % GBK || p.k_per_split % GBK) return false;
+  return (p.M / GBM) * (p.N / bn) * splits >= 128;        // enough blocks to fill the chip
 }
-
 static bool fast128_eligible(const GemmParams& p, int splits) {
   if (p.M % FBM || p.N % FBN) return false;
   if (p.K % FBK || p.k_per_split % FBK) return false;
@@ -398,35 +401,54 @@ bool gemm_fast_eligible(const GemmParams& p, int splits) {
   if (p.c_f32 && !(p.epi == EPI_NONE || p.epi == EPI_TANH)) return false;   // f32 outputs: plain / tanh only
   if ((p.ldc % 4) || (p.ld_aux % 4)) return false;
   if ((long long)p.k_per_split * splits < p.K) return false;
-  return fast256_eligible(p, splits) || fast128_eligible(p, splits);
+  return pipe_eligible(p, splits, 256) || pipe_eligible(p, splits, 128) || fast128_eligible(p, splits);
 }
 
-static int use256() {
+static int tile_pref() {      // MMSIM_GEMM_TILE: 0 auto (default), 1 = old 256x128x64 kernel only, 2 = pipelined BN=128 only
   static int v = -1;
-  if (v < 0) { const char* e = getenv("MMSIM_GEMM_TILE"); v = (e && e[0] == '1') ? 0 : 1; }   // MMSIM_GEMM_TILE=128: 256x128 only
+  if (v < 0) { const char* e = getenv("MMSIM_GEMM_TILE"); v = e ? atoi(e) : 0; }
   return v;
 }
 
+template <int BN>
+static void launch_pipe(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s) {
+  p.tiles_m = p.M / GBM; p.tiles_n = p.N / BN; p.splits = splits;
+  dim3 grid(p.tiles_m * p.tiles_n * splits), block(512);
+  const size_t lds = 8 * 64 * EP_PITCH * 4;      // 136 KiB: epilogue staging (8 waves x 64 x 68 floats) >= the operand ring
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<false, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<false, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<true, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<true, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    done = true;
+  }
+  if (!trans_a && b_kmajor) hipLaunchKernelGGL((gemm_fast256_kernel<false, true, BN>), grid, block, lds, s, p);
+  else if (!trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_fast256_kernel<false, false, BN>), grid, block, lds, s, p);
+  else if (trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_fast256_kernel<true, false, BN>), grid, block, lds, s, p);
+  else hipLaunchKernelGGL((gemm_fast256_kernel<true, true, BN>), grid, block, lds, s, p);
+}
+
 void gemm_fast_launch(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s) {
-  // wgrad-shaped products (A transposed, long reduction, few output tiles) keep the 256x128 tile: more tiles per split
-  const bool prefer256 = use256() && !trans_a;
-  if ((prefer256 || !fast128_eligible(p, splits)) && fast256_eligible(p, splits)) {
-    p.tiles_m = p.M / GBM; p.tiles_n = p.N / GBN; p.splits = splits;
-    dim3 grid(p.tiles_m * p.tiles_n * splits), block(512);
-    const size_t lds = 8 * 64 * EP_PITCH * 4;            // 136 KiB: the epilogue staging (8 waves x 64 x 68 floats) exceeds the 128-KiB ring
-    static bool done256 = false;
-    if (!done256) {
-      (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      done256 = true;
+  const int pref = tile_pref();
+  // wgrad-shaped products (A transposed: few output tiles, long reduction, split-K) take the narrower tile: more tiles
+  // per split and half the atomic traffic per block; everything else prefers 256x256 (twice the flop per staged byte)
+  if (pref != 1) {
+    const bool e256 = pipe_eligible(p, splits, 256), e128 = pipe_eligible(p, splits, 128);
+    if (!trans_a) {
+      if (e256 && pref != 2) { launch_pipe<256>(p, trans_a, b_kmajor, splits, s); return; }
+      if (e128) { launch_pipe<128>(p, trans_a, b_kmajor, splits, s); return; }
+    } else {
+      // wgrad-shaped products (A transposed, long reduction, split-K with atomics): measured on the text shapes, the
+      // 256x256 pipelined kernel wins when the output has >= 32 such tiles (FFN, QKV: 960-1000 / 770 TFLOP/s), the
+      // 256x128x64 kernel below wins on small outputs (attention-output projection: 720 vs 590)
+      const int t256 = (p.M / GBM) * (p.N / 256);
+      if ((e256 && t256 >= 32 && t256 * splits >= 160) || pref == 3) { launch_pipe<256>(p, trans_a, b_kmajor, splits, s); return; }
+      if (!fast128_eligible(p, splits)) {
+        if (e128) { launch_pipe<128>(p, trans_a, b_kmajor, splits, s); return; }
+        if (e256) { launch_pipe<256>(p, trans_a, b_kmajor, splits, s); return; }
+      }
     }
-    if (!trans_a && b_kmajor) hipLaunchKernelGGL((gemm_fast256_kernel<false, true>), grid, block, lds, s, p);
-    else if (!trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_fast256_kernel<false, false>), grid, block, lds, s, p);
-    else if (trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_fast256_kernel<true, false>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((gemm_fast256_kernel<true, true>), grid, block, lds, s, p);
-    return;
   }
   p.tiles_m = p.M / FBM; p.tiles_n = p.N / FBN;
   p.splits = splits;

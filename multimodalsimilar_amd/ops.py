@@ -4,6 +4,8 @@ Every wrapper validates dtype / device / contiguity / shape in Python and raises
 launched, then passes raw device pointers and the current HIP stream to libmmsim_hip.so.
 torch is used for memory and streams only.
 """
+import os
+
 import torch
 
 from ._lib import lib, MmsimError
@@ -97,12 +99,20 @@ def gemm(a, b, c, *, trans_a=False, b_kmajor=True, bias=None, epilogue=EPI_NONE,
 
 
 def pick_split_k(M, N, K):
-    """wgrad-style products have few output tiles and a long reduction: split K until ~2 waves of blocks."""
+    """Split-K factor for wgrad-style products (few output tiles, long reduction).  Mirrors the tile choice of
+    csrc/gemm_fast.hip: outputs with >= 32 tiles of 256x256 run the pipelined 256x256 kernel with ~192-256 blocks,
+    smaller ones the 256x128 kernel with ~256-512 blocks (the split-K partial sums leave as fp32 atomics)."""
+    mult = int(os.environ.get("MMSIM_SPLITK_MULT", "1"))
+    if M % 256 == 0 and N % 256 == 0 and (M // 256) * (N // 256) >= 32:
+        t, s = (M // 256) * (N // 256), 1
+        while t * s < 192 and K // (s * 2) >= 512:
+            s *= 2
+        return s * mult
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     s = 1
     while tiles * s < 512 and K // (s * 2) >= 512:
         s *= 2
-    return s
+    return s * mult
 
 
 def attn_fwd(qkv, mask, ctx, lse, B, S, heads, H, dropout_p=0.0, seed=0, stream_id=0):
