@@ -387,6 +387,195 @@ __global__ __launch_bounds__(512, 2) void gemm_fast256_kernel(GemmParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent form of the pipelined kernel: one workgroup per CU walks its share of the (split, tile) list, and the
+// LDS-DMA prologue of tile k+1 (four K-slices) is issued BEFORE the epilogue of tile k, so the epilogue's stores and
+// the next tile's first loads overlap instead of each tile paying prologue latency + epilogue tail back to back
+// (at K = 1024 those were ~40 % of a tile's time).  The epilogue is staged through a small per-wave LDS region that
+// sits BESIDE the operand ring (16 rows x 64 fp32 per wave, XOR-swizzled 16-B slots: conflict-free both ways), one
+// 16-row MFMA tile row at a time, and leaves as whole 128-B / 256-B row segments.
+template <int EPI, int CMODE>
+__device__ __forceinline__ void chunk_epilogue(const GemmParams& p, const f4 (&a)[4], int row0, int col0, int lane,
+                                               bool first_split, float* stg) {
+  const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) *reinterpret_cast<f4*>(stg + r * 64 + (((j * 4 + g) ^ r) << 2)) = a[j];
+  if (CMODE == 3) {
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr)
+      atomicAdd(reinterpret_cast<float*>(p.C) + (size_t)(row0 + rr) * p.ldc + col0 + lane,
+                stg[rr * 64 + ((((lane >> 2) ^ rr) << 2) | (lane & 3))] * p.alpha);
+    return;
+  }
+  const int c4 = lane & 15, n = col0 + c4 * 4;
+  const bool add_bias = (p.bias != nullptr) && first_split;
+  const float4 bias = add_bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int rr = it * 4 + g;
+    const size_t m = (size_t)(row0 + rr);
+    const f4 x = *reinterpret_cast<const f4*>(stg + rr * 64 + ((c4 ^ rr) << 2));
+    float v[4] = {x[0] * p.alpha + bias.x, x[1] * p.alpha + bias.y, x[2] * p.alpha + bias.z, x[3] * p.alpha + bias.w};
+    if (EPI == EPI_GELU) {
+      bf4 pre = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+      *reinterpret_cast<bf4*>(p.aux_out + m * p.ld_aux + n) = pre;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_f(bf2f(pre[e]));
+    } else if (EPI == EPI_MUL_GELU_GRAD) {
+      const bf4 y = *reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(bf2f(y[e]));
+    } else if (EPI == EPI_ADD) {
+      const bf4 y = *reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += bf2f(y[e]);
+    } else if (EPI == EPI_TANH) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+    }
+    if (CMODE == 0) {
+      bf4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+      *reinterpret_cast<bf4*>(reinterpret_cast<bf16*>(p.C) + m * p.ldc + n) = o;
+    } else {
+      float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
+      if (CMODE == 1) {
+        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        const float4 old = *reinterpret_cast<const float4*>(c);
+        *reinterpret_cast<float4*>(c) = make_float4(v[0] + old.x, v[1] + old.y, v[2] + old.z, v[3] + old.w);
+      }
+    }
+  }
+}
+
+template <int MT, int EPI, int CMODE>
+__device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 (&acc)[MT][4], int row0, int col0, int lane, bool fs,
+                                              float* stg) {
+#pragma unroll
+  for (int i = 0; i < MT; ++i) chunk_epilogue<EPI, CMODE>(p, acc[i], row0 + i * 16, col0, lane, fs, stg);
+}
+
+template <bool TA, bool TB_KMAJOR, int BN>
+__global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmParams p) {
+  constexpr int MT = BN == 256 ? 8 : 4;
+  constexpr int WROWS = MT * 16;
+  constexpr int A_BYTES = GBM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
+  constexpr int LPS = 2 + BN / 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = BN == 256 ? (wave >> 2) : (wave >> 1), wn = BN == 256 ? (wave & 3) : (wave & 1);
+  float* stg = reinterpret_cast<float*>(smem + G_SLOTS * STAGE) + wave * (16 * 64);
+
+  // this block's share of the (split, tile) list: XCD x owns one contiguous chunk, its blocks interleave inside it
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int nwg = ntiles * p.splits;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int cstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int cend = cstart + q8 + (xcd < r8 ? 1 : 0);
+  int w = cstart + idx;
+  if (w >= cend) return;
+
+  int split, m0, n0, kbeg, nk;
+  auto decode = [&](int wg, int& sp, int& mm, int& nn, int& kb, int& nks) {
+    sp = wg / ntiles;
+    const int tile = wg - sp * ntiles;
+    mm = (tile / p.tiles_n) * GBM; nn = (tile % p.tiles_n) * BN;
+    kb = sp * p.k_per_split;
+    nks = (min(p.K, kb + p.k_per_split) - kb) / GBK;
+  };
+  auto prologue = [&](int mm, int nn, int kb, int nks) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < nks) {
+        dma_tile32<TA, GBM>(p.A, p.lda, mm, kb + t * GBK, smem + t * STAGE, wave, lane);
+        dma_tile32<!TB_KMAJOR, BN>(p.B, p.ldb, nn, kb + t * GBK, smem + t * STAGE + A_BYTES, wave, lane);
+      }
+  };
+  decode(w, split, m0, n0, kbeg, nk);
+  prologue(m0, n0, kbeg, nk);
+
+  while (true) {
+    f4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+    bf8 afA[MT], bfA[4], afB[MT], bfB[4];
+    {
+      const int ahead = min(nk - 1, 3);
+      if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
+      else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfA[j] = gfrag<!TB_KMAJOR, BN>(smem + A_BYTES, wn * 64 + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) afA[i] = gfrag<TA, GBM>(smem, wm * WROWS + i * 16, lane);
+    }
+#define GEMMP_STEP(af0, bf0, af1, bf1, T)                                                                           \
+  {                                                                                                                 \
+    const int t_ = (T);                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    if (t_ + 1 < nk) {                                                                                              \
+      const int ahead = min(nk - 2 - t_, 2);                                                                        \
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");                                \
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");                               \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
+      __builtin_amdgcn_s_barrier();                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      if (t_ + 4 < nk) {                                                                                            \
+        char* ns = smem + (t_ & 3) * STAGE;                                                                         \
+        dma_tile32<TA, GBM>(p.A, p.lda, m0, kbeg + (t_ + 4) * GBK, ns, wave, lane);                                 \
+        dma_tile32<!TB_KMAJOR, BN>(p.B, p.ldb, n0, kbeg + (t_ + 4) * GBK, ns + A_BYTES, wave, lane);                \
+      }                                                                                                             \
+      const char* la = smem + ((t_ + 1) & 3) * STAGE;                                                               \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) bf1[j] = gfrag<!TB_KMAJOR, BN>(la + A_BYTES, wn * 64 + j * 16, lane); \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) af1[i] = gfrag<TA, GBM>(la, wm * WROWS + i * 16, lane);        \
+    }                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                  \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j], af0[i], acc[i][j], 0, 0, 0);                    \
+  }
+    for (int t = 0; t < nk; t += 2) {
+      GEMMP_STEP(afA, bfA, afB, bfB, t)
+      if (t + 1 < nk) GEMMP_STEP(afB, bfB, afA, bfA, t + 1)
+    }
+#undef GEMMP_STEP
+    // every wave has read its last fragments (lgkmcnt(0) above); after this barrier the ring may be refilled
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const int wn_ = w + bpx;
+    const bool has_next = wn_ < cend;
+    int split2 = 0, m2 = 0, n2 = 0, kb2 = 0, nk2 = 0;
+    if (has_next) {
+      decode(wn_, split2, m2, n2, kb2, nk2);
+      prologue(m2, n2, kb2, nk2);                 // in flight while the epilogue below runs
+    }
+    const bool fs = split == 0;
+    const int row0 = m0 + wm * WROWS, col0 = n0 + wn * 64;
+    if (!p.c_f32) {
+      switch (p.epi) {
+        case EPI_GELU: tile_epilogue<MT, EPI_GELU, 0>(p, acc, row0, col0, lane, fs, stg); break;
+        case EPI_MUL_GELU_GRAD: tile_epilogue<MT, EPI_MUL_GELU_GRAD, 0>(p, acc, row0, col0, lane, fs, stg); break;
+        case EPI_ADD: tile_epilogue<MT, EPI_ADD, 0>(p, acc, row0, col0, lane, fs, stg); break;
+        case EPI_TANH: tile_epilogue<MT, EPI_TANH, 0>(p, acc, row0, col0, lane, fs, stg); break;
+        default: tile_epilogue<MT, EPI_NONE, 0>(p, acc, row0, col0, lane, fs, stg); break;
+      }
+    } else if (p.atomic) tile_epilogue<MT, EPI_NONE, 3>(p, acc, row0, col0, lane, fs, stg);
+    else if (p.accum) tile_epilogue<MT, EPI_NONE, 2>(p, acc, row0, col0, lane, fs, stg);
+    else if (p.epi == EPI_TANH) tile_epilogue<MT, EPI_TANH, 1>(p, acc, row0, col0, lane, fs, stg);
+    else tile_epilogue<MT, EPI_NONE, 1>(p, acc, row0, col0, lane, fs, stg);
+    if (!has_next) break;
+    w = wn_; split = split2; m0 = m2; n0 = n2; kbeg = kb2; nk = nk2;
+  }
+}
+
 static bool pipe_eligible(const GemmParams& p, int splits, int bn) {
   if (p.M % GBM || p.N % bn || p.K % GBK || p.k_per_split % GBK) return false;
   return (p.M / GBM) * (p.N / bn) * splits >= 128;        // enough blocks to fill the chip
@@ -410,8 +599,46 @@ static int tile_pref() {      // MMSIM_GEMM_TILE: 0 auto (default), 1 = old 256x
   return v;
 }
 
+// MMSIM_GEMM_PERSIST=1 selects the persistent form.  Measured (round 1): no gain on the forward layout (the epilogue
+// is executed by the same waves, so only the ~2 us prologue latency per tile is hidden) and a loss on the layouts with
+// transposed operands, whose instantiations spill inside the K loop at 256 VGPRs; it stays opt-in until the address
+// arithmetic is moved to immediates / SGPRs (DESIGN.md "open items").
+static int persist_pref() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MMSIM_GEMM_PERSIST"); v = e ? atoi(e) : 0; }
+  return v;
+}
+static int num_cus() {
+  static int n = 0;
+  if (!n) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); n = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+  return n;
+}
+
+template <int BN>
+static void launch_pers(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s) {
+  p.tiles_m = p.M / GBM; p.tiles_n = p.N / BN; p.splits = splits;
+  const int nwg = p.tiles_m * p.tiles_n * splits;
+  int nblk = (num_cus() / 8) * 8;                      // one workgroup per CU, a multiple of the 8 XCDs
+  if (nblk > ((nwg + 7) / 8) * 8) nblk = ((nwg + 7) / 8) * 8;
+  dim3 grid(nblk), block(512);
+  const size_t lds = G_SLOTS * (GBM * 64 + BN * 64) + 8 * 16 * 64 * 4;      // operand ring + per-wave epilogue staging
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<false, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<false, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<true, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<true, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    done = true;
+  }
+  if (!trans_a && b_kmajor) hipLaunchKernelGGL((gemm_pers_kernel<false, true, BN>), grid, block, lds, s, p);
+  else if (!trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_pers_kernel<false, false, BN>), grid, block, lds, s, p);
+  else if (trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_pers_kernel<true, false, BN>), grid, block, lds, s, p);
+  else hipLaunchKernelGGL((gemm_pers_kernel<true, true, BN>), grid, block, lds, s, p);
+}
+
 template <int BN>
 static void launch_pipe(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s) {
+  if (persist_pref()) { launch_pers<BN>(p, trans_a, b_kmajor, splits, s); return; }
   p.tiles_m = p.M / GBM; p.tiles_n = p.N / BN; p.splits = splits;
   dim3 grid(p.tiles_m * p.tiles_n * splits), block(512);
   const size_t lds = 8 * 64 * EP_PITCH * 4;      // 136 KiB: epilogue staging (8 waves x 64 x 68 floats) >= the operand ring
