@@ -178,7 +178,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  gemm_epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, lane, split == 0);
+  // staged epilogue (whole cache-line row segments; the operand stages are free after the last barrier)
+  {
+    const bool fs = split == 0;
+    const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;
+    float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
+    if (!p.c_f32) fast_epilogue_epi<0, true>(p, acc, row0, col0, lane, fs, stg);
+    else if (p.atomic) fast_epilogue<EPI_NONE, 3, true>(p, acc, row0, col0, lane, fs, stg);
+    else if (p.accum) fast_epilogue<EPI_NONE, 2, true>(p, acc, row0, col0, lane, fs, stg);
+    else if (p.epi == EPI_TANH) fast_epilogue<EPI_TANH, 1, true>(p, acc, row0, col0, lane, fs, stg);
+    else if (p.epi == EPI_NONE) fast_epilogue<EPI_NONE, 1, true>(p, acc, row0, col0, lane, fs, stg);
+    else gemm_epilogue(p, acc, row0, col0, lane, fs);          // f32 output with a fused epilogue: direct form
+  }
 }
 
 // C-ABI -- see include/mmsim_hip.h for the contract.

@@ -90,79 +90,6 @@ __device__ __forceinline__ bf8 ffrag(const char* lds, int rbase, int ks, int lan
   }
 }
 
-// Epilogue for full tiles, staged through LDS so that every global access is row-contiguous: the wave's 64x64
-// fp32 tile is written to its private LDS region (the operand ring is free by then) and read back one row segment
-// per 16 lanes: 128-B bf16 / 256-B fp32 stores and aux loads (whole cache lines), and for split-K one 256-B
-// contiguous atomic wave-instruction per row (the shape float atomics run at full rate in, MI355X_MICROARCH.md).
-// CMODE: 0 bf16 store, 1 f32 store, 2 f32 +=, 3 f32 atomic add.
-#define EP_PITCH 68     // floats per staged row (64 + 4 pad: 16-byte aligned rows)
-template <int EPI, int CMODE>
-__device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][4], int row0, int col0, int lane, bool first_split,
-                                              float* tile) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f4*>(tile + (i * 16 + (lane & 15)) * EP_PITCH + j * 16 + (lane >> 4) * 4) = acc[i][j];
-  if (CMODE == 3) {
-#pragma unroll 8
-    for (int r = 0; r < 64; ++r)
-      atomicAdd(reinterpret_cast<float*>(p.C) + (size_t)(row0 + r) * p.ldc + col0 + lane, tile[r * EP_PITCH + lane] * p.alpha);
-    return;
-  }
-  const int c4 = (lane & 15) * 4, n = col0 + c4;
-  const bool add_bias = (p.bias != nullptr) && first_split;
-  const float4 bias = add_bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int r = it * 4 + (lane >> 4);
-    const size_t m = (size_t)(row0 + r);
-    const f4 a = *reinterpret_cast<const f4*>(tile + r * EP_PITCH + c4);
-    float v[4] = {a[0] * p.alpha + bias.x, a[1] * p.alpha + bias.y, a[2] * p.alpha + bias.z, a[3] * p.alpha + bias.w};
-    if (EPI == EPI_GELU) {
-      bf4 pre = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-      *reinterpret_cast<bf4*>(p.aux_out + m * p.ld_aux + n) = pre;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = gelu_f(bf2f(pre[e]));
-    } else if (EPI == EPI_MUL_GELU_GRAD) {
-      const bf4 x = *reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(bf2f(x[e]));
-    } else if (EPI == EPI_ADD) {
-      const bf4 x = *reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += bf2f(x[e]);
-    } else if (EPI == EPI_TANH) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
-    }
-    if (CMODE == 0) {
-      bf4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-      *reinterpret_cast<bf4*>(reinterpret_cast<bf16*>(p.C) + m * p.ldc + n) = o;
-    } else {
-      float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
-      if (CMODE == 1) {
-        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        const float4 old = *reinterpret_cast<const float4*>(c);
-        *reinterpret_cast<float4*>(c) = make_float4(v[0] + old.x, v[1] + old.y, v[2] + old.z, v[3] + old.w);
-      }
-    }
-  }
-}
-
-template <int CMODE>
-__device__ __forceinline__ void fast_epilogue_epi(const GemmParams& p, f4 (&acc)[4][4], int row0, int col0, int lane, bool first_split,
-                                                  float* tile) {
-  switch (p.epi) {
-    case EPI_GELU: fast_epilogue<EPI_GELU, CMODE>(p, acc, row0, col0, lane, first_split, tile); break;
-    case EPI_MUL_GELU_GRAD: fast_epilogue<EPI_MUL_GELU_GRAD, CMODE>(p, acc, row0, col0, lane, first_split, tile); break;
-    case EPI_ADD: fast_epilogue<EPI_ADD, CMODE>(p, acc, row0, col0, lane, first_split, tile); break;
-    case EPI_TANH: fast_epilogue<EPI_TANH, CMODE>(p, acc, row0, col0, lane, first_split, tile); break;
-    default: fast_epilogue<EPI_NONE, CMODE>(p, acc, row0, col0, lane, first_split, tile); break;
-  }
-}
-
 template <bool TA, bool TB_KMAJOR>
 __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
