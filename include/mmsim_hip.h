@@ -129,15 +129,16 @@ int mmsim_bn_apply(const void* z, const float* scale, const float* shift, const 
 /* out[b,c] = mul * sum_hw act(scale*z+shift) * (other ? other : 1): SE squeeze / global pool (mul = 1/HW), SE dgate. */
 int mmsim_pool_bn_act(const void* z, const float* scale, const float* shift, const void* other, float* out, int B,
                       int HW, int C, int act_silu, float mul, void* stream);
-/* Squeeze-excite: hr = W_reduce s + b_reduce (saved pre-activation); gate = sigmoid(W_expand silu(hr) + b_expand).
+/* Squeeze-excite: hr = W_reduce s + b_reduce (saved pre-activation; hs = silu(hr) saved too); gate = sigmoid(W_expand silu(hr) + b_expand).
  * weT [RD][C] receives conv_expand.weight transposed (kept for the backward of the same step).  Backward: from
  * dgate [B,C] produces dr [B,RD], ds [B,C] (gradient of the squeezed input) and accumulates the four parameter
  * gradients (dweT [RD][C]: scratch). */
 int mmsim_se_mlp_fwd(const float* s, const float* w_reduce, const float* b_reduce, const float* w_expand,
-                     const float* b_expand, float* weT, float* hr, float* gate, int B, int C, int RD, void* stream);
-int mmsim_se_mlp_bwd(const float* dgate, const float* gate, const float* hr, const float* s, const float* w_reduce,
-                     const float* weT, float* dr, float* ds, float* dweT, float* dw_reduce, float* db_reduce,
-                     float* dw_expand, float* db_expand, int B, int C, int RD, void* stream);
+                     const float* b_expand, float* weT, float* hr, float* hs, float* gate, int B, int C, int RD,
+                     void* stream);
+int mmsim_se_mlp_bwd(const float* dgate, const float* gate, const float* hr, const float* hs, const float* s,
+                     const float* w_reduce, const float* weT, float* dr, float* ds, float* dweT, float* dw_reduce,
+                     float* db_reduce, float* dw_expand, float* db_expand, int B, int C, int RD, void* stream);
 /* BatchNorm (+SiLU, +SE gate) backward: da = (gate ? dy*gate + dsq/hw : dy) * (act ? silu'(scale*z+shift) : 1);
  * dz = scale*(da - mean(da) - zhat*mean(da*zhat)); dgamma += sum da*zhat; dbeta += sum da.
  * sums [2][C] must be zero on entry unless sums_ready (already produced by mmsim_dwconv_bwd_data). */

@@ -198,8 +198,8 @@ enum { SE_POST_NONE = 0, SE_POST_SIGMOID = 1, SE_POST_MUL_DSILU = 2 };   // MUL_
 
 __global__ __launch_bounds__(256) void se_rowdot_kernel(const float* __restrict__ W, const float* __restrict__ x,
                                                         const float* __restrict__ aux, const float* __restrict__ bias,
-                                                        const float* __restrict__ aux2, float* out, int B, int C, int R,
-                                                        int pre, int post) {
+                                                        const float* __restrict__ aux2, float* out, float* out_silu, int B,
+                                                        int C, int R, int pre, int post) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r = blockIdx.x;
   const float* w = W + (size_t)r * C;
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256) void se_rowdot_kernel(const float* __restrict_
       if (bias) a += bias[r];
       if (post == SE_POST_MUL_DSILU) a *= silu_grad_f(aux2[(size_t)b * R + r]);
       out[(size_t)b * R + r] = a;
+      if (out_silu) out_silu[(size_t)b * R + r] = silu_f(a);
     }
   }
 }
@@ -258,30 +259,47 @@ __global__ void se_transpose_kernel(const float* in, float* out, int rows, int c
   else out[(size_t)c * rows + r] = in[i];
 }
 
-// weight gradients, thread per (r, c) with c fastest (coalesced), reductions over the batch:
-//   dWr[r][c] += sum_b dr[b,r] * s[b,c]      dWeT[r][c] = sum_b dpe[b,c] * silu(hr[b,r]),  dpe = dgate*g*(1-g)
+// weight gradients (reductions over the batch).  One wave per (64 channels, 16 reduce-rows, quarter of the batch):
+// the per-image vectors dpe[b,c], s[b,c] are loaded once per image and reused for 16 rows; hs / dr values are
+// wave-uniform (scalar operands).  Partial sums leave as atomics (4 adders per address).
+//   dWr[r][c] += sum_b dr[b,r] * s[b,c]      dWeT[r][c] += sum_b dpe[b,c] * hs[b,r]   (hs = silu(hr), dpe = dgate*g*(1-g))
 //   dbr[r] += sum_b dr[b,r]                  dbe[c] += sum_b dpe[b,c]
-__global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
-                                                       const float* __restrict__ dr, const float* __restrict__ hr,
-                                                       const float* __restrict__ s, float* dWr, float* dbr, float* dWeT, float* dbe,
-                                                       int B, int C, int R) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= C * R) return;
-  const int r = idx / C, c = idx % C;
-  float ae = 0.f, ar = 0.f, ab = 0.f, abr = 0.f;
-#pragma unroll 4
-  for (int b = 0; b < B; ++b) {
-    const float g = gate[(size_t)b * C + c];
-    const float d = dgate[(size_t)b * C + c] * g * (1.f - g);
-    const float rr = dr[(size_t)b * R + r];
-    ae += d * silu_f(hr[(size_t)b * R + r]);
-    ar += rr * s[(size_t)b * C + c];
-    ab += d; abr += rr;
+__global__ __launch_bounds__(64) void se_wgrad_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                      const float* __restrict__ dr, const float* __restrict__ hs,
+                                                      const float* __restrict__ s, float* dWr, float* dbr, float* dWeT, float* dbe,
+                                                      int B, int C, int R) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int r0 = blockIdx.y * 16;
+  const int bq = (B + 3) / 4, b0 = blockIdx.z * bq, b1 = min(B, b0 + bq);
+  const bool cok = c < C;
+  float ae[16], ar[16], ab = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { ae[k] = 0.f; ar[k] = 0.f; }
+  for (int b = b0; b < b1; ++b) {
+    float d = 0.f, sv = 0.f;
+    if (cok) {
+      const float g = gate[(size_t)b * C + c];
+      d = dgate[(size_t)b * C + c] * g * (1.f - g);
+      sv = s[(size_t)b * C + c];
+    }
+    ab += d;
+    const float* hrow = hs + (size_t)b * R + r0;
+    const float* drow = dr + (size_t)b * R + r0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (r0 + k < R) { ae[k] += d * hrow[k]; ar[k] += drow[k] * sv; }
   }
-  dWeT[idx] = ae;
-  dWr[idx] += ar;
-  if (r == 0) dbe[c] += ab;
-  if (c == 0) dbr[r] += abr;
+  if (cok) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (r0 + k < R) { atomicAdd(dWeT + (size_t)(r0 + k) * C + c, ae[k]); atomicAdd(dWr + (size_t)(r0 + k) * C + c, ar[k]); }
+    if (blockIdx.y == 0) atomicAdd(dbe + c, ab);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 16 && r0 + threadIdx.x < R) {
+    float a = 0.f;
+    for (int b = b0; b < b1; ++b) a += dr[(size_t)b * R + r0 + threadIdx.x];
+    atomicAdd(dbr + r0 + threadIdx.x, a);
+  }
 }
 
 // ------------------------------------------------------------------ BN (+SiLU, +SE gate) backward
@@ -813,34 +831,36 @@ extern "C" int mmsim_pool_bn_act(const void* z, const float* scale, const float*
 
 /* weT: scratch [RD][C] receiving conv_expand.weight transposed (reused by the backward of the same step) */
 extern "C" int mmsim_se_mlp_fwd(const float* s, const float* w_reduce, const float* b_reduce, const float* w_expand,
-                                const float* b_expand, float* weT, float* hr, float* gate, int B, int C, int RD, void* stream) {
-  MMSIM_REQUIRE(s && w_reduce && b_reduce && w_expand && b_expand && weT && hr && gate && B > 0 && C > 0 && RD > 0, "se_mlp_fwd: bad arguments");
+                                const float* b_expand, float* weT, float* hr, float* hs, float* gate, int B, int C, int RD,
+                                void* stream) {
+  MMSIM_REQUIRE(s && w_reduce && b_reduce && w_expand && b_expand && weT && hr && hs && gate && B > 0 && C > 0 && RD > 0, "se_mlp_fwd: bad arguments");
   MMSIM_REQUIRE(C % 8 == 0 && RD <= 128, "se_mlp_fwd: C must be a multiple of 8 and RD <= 128");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(se_transpose_kernel, dim3((C * RD + 255) / 256), dim3(256), 0, st, w_expand, weT, C, RD, 0);
   hipLaunchKernelGGL(se_rowdot_kernel, dim3(RD, (B + 7) / 8), dim3(256), 0, st, w_reduce, s, (const float*)nullptr, b_reduce,
-                     (const float*)nullptr, hr, B, C, RD, SE_PRE_NONE, SE_POST_NONE);
+                     (const float*)nullptr, hr, hs, B, C, RD, SE_PRE_NONE, SE_POST_NONE);
   hipLaunchKernelGGL(se_colmix_kernel, dim3((C + 63) / 64, (B + 3) / 4), dim3(256), 0, st, weT, hr, b_expand, gate, B, C, RD, SE_PRE_SILU,
                      SE_POST_SIGMOID);
   return mmsim_check_launch("se_mlp_fwd");
 }
 
 /* dr [B,RD], ds [B,C]: outputs; dweT: scratch [RD][C].  Weight / bias gradients are accumulated. */
-extern "C" int mmsim_se_mlp_bwd(const float* dgate, const float* gate, const float* hr, const float* s, const float* w_reduce,
-                                const float* weT, float* dr, float* ds, float* dweT, float* dw_reduce, float* db_reduce,
-                                float* dw_expand, float* db_expand, int B, int C, int RD, void* stream) {
-  MMSIM_REQUIRE(dgate && gate && hr && s && w_reduce && weT && dr && ds && dweT && dw_reduce && db_reduce && dw_expand && db_expand,
+extern "C" int mmsim_se_mlp_bwd(const float* dgate, const float* gate, const float* hr, const float* hs, const float* s,
+                                const float* w_reduce, const float* weT, float* dr, float* ds, float* dweT, float* dw_reduce,
+                                float* db_reduce, float* dw_expand, float* db_expand, int B, int C, int RD, void* stream) {
+  MMSIM_REQUIRE(dgate && gate && hr && hs && s && w_reduce && weT && dr && ds && dweT && dw_reduce && db_reduce && dw_expand && db_expand,
                 "se_mlp_bwd: null operand");
   MMSIM_REQUIRE(C % 8 == 0 && RD <= 128, "se_mlp_bwd: C must be a multiple of 8 and RD <= 128");
   hipStream_t st = (hipStream_t)stream;
   // dr[b,j] = (sum_c We[c,j] dpe[b,c]) * silu'(hr[b,j]),  dpe = dgate * g * (1 - g)
-  hipLaunchKernelGGL(se_rowdot_kernel, dim3(RD, (B + 7) / 8), dim3(256), 0, st, weT, dgate, gate, (const float*)nullptr, hr, dr, B, C, RD,
-                     SE_PRE_DSIGMOID, SE_POST_MUL_DSILU);
+  hipLaunchKernelGGL(se_rowdot_kernel, dim3(RD, (B + 7) / 8), dim3(256), 0, st, weT, dgate, gate, (const float*)nullptr, hr, dr,
+                     (float*)nullptr, B, C, RD, SE_PRE_DSIGMOID, SE_POST_MUL_DSILU);
   // ds[b,c] = sum_j Wr[j,c] dr[b,j]
   hipLaunchKernelGGL(se_colmix_kernel, dim3((C + 63) / 64, (B + 3) / 4), dim3(256), 0, st, w_reduce, dr, (const float*)nullptr, ds, B, C, RD,
                      SE_PRE_NONE, SE_POST_NONE);
-  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * RD + 255) / 256), dim3(256), 0, st, dgate, gate, dr, hr, s, dw_reduce, db_reduce, dweT,
-                     db_expand, B, C, RD);
+  (void)hipMemsetAsync(dweT, 0, (size_t)C * RD * sizeof(float), st);
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 63) / 64, (RD + 15) / 16, 4), dim3(64), 0, st, dgate, gate, dr, hs, s, dw_reduce, db_reduce,
+                     dweT, db_expand, B, C, RD);
   hipLaunchKernelGGL(se_transpose_kernel, dim3((C * RD + 255) / 256), dim3(256), 0, st, dweT, dw_expand, RD, C, 1);
   return mmsim_check_launch("se_mlp_bwd");
 }

@@ -228,21 +228,22 @@ __global__ __launch_bounds__(256) void row_reduce_partials_kernel(const float* _
   if (wv == 0 && i < n) atomicAdd(out + i, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
+template <int NC>     // NC = ceil(H / 256) chunks per lane: keeps the per-lane column accumulators at 3*4*NC registers
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dh_a, const bf16* dh_b, const bf16* y, const float* mean_i,
                                                      const float* rstd_i, const float* gamma, bf16* dy, bf16* dt,
                                                      float* parts, int M, int H, int rows_per_wave, Drop dr) {
   __shared__ float red[3][4][64 * 4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r0 = (blockIdx.x * 4 + wv) * rows_per_wave, r1 = min(M, r0 + rows_per_wave);
-  float4 ag[MAXC], ab[MAXC], abias[MAXC];
+  float4 ag[NC], ab[NC], abias[NC];
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) ag[c] = ab[c] = abias[c] = make_float4(0, 0, 0, 0);
+  for (int c = 0; c < NC; ++c) ag[c] = ab[c] = abias[c] = make_float4(0, 0, 0, 0);
   for (int row = r0; row < r1; ++row) {
     const float mean = mean_i[row], rstd = rstd_i[row];
-    float4 g[MAXC], xh[MAXC];
+    float4 g[NC], xh[NC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const int col = lane * 4 + c * 256;
       if (col < H) {
         float4 d = ld4(dh_a + (size_t)row * H + col);
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dh_a, const bf1
     }
     s1 = wave_sum(s1) / H; s2 = wave_sum(s2) / H;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const int col = lane * 4 + c * 256;
       if (col < H) {
         const float4 o = make_float4(rstd * (g[c].x - s1 - xh[c].x * s2), rstd * (g[c].y - s1 - xh[c].y * s2),
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dh_a, const bf1
   // cross-wave reduction through LDS, then the block's partial column sums go to its slot parts[blockIdx.x][3][H]
   // (a second launch sums the slots: hundreds of blocks adding atomically into the same H addresses serialise)
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
+  for (int c = 0; c < NC; ++c) {
     const int col = lane * 4 + c * 256;
     if (c * 256 >= H) break;   // uniform
     __syncthreads();
@@ -430,9 +431,14 @@ extern "C" int mmsim_ln_bwd(const void* dh_a, const void* dh_b, const void* y, c
   if (rpw < 1) rpw = 1;
   const int nblk = (M + 4 * rpw - 1) / (4 * rpw);
   MMSIM_REQUIRE(scratch && scratch_floats >= (unsigned long long)nblk * 3 * H, "ln_bwd: scratch too small (need blocks*3*H floats)");
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16*)dh_a, (const bf16*)dh_b,
-                     (const bf16*)y, mean, rstd, gamma, (bf16*)dy, (bf16*)dt, scratch, M, H, rpw,
-                     make_drop(dropout_p, seed, stream_id));
+#define LN_BWD_LAUNCH(NCV)                                                                                           \
+  hipLaunchKernelGGL((ln_bwd_kernel<NCV>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16*)dh_a, (const bf16*)dh_b, \
+                     (const bf16*)y, mean, rstd, gamma, (bf16*)dy, (bf16*)dt, scratch, M, H, rpw,                  \
+                     make_drop(dropout_p, seed, stream_id))
+  const int nc = (H + 255) / 256;
+  if (nc <= 1) LN_BWD_LAUNCH(1); else if (nc == 2) LN_BWD_LAUNCH(2); else if (nc == 3) LN_BWD_LAUNCH(3);
+  else if (nc == 4) LN_BWD_LAUNCH(4); else LN_BWD_LAUNCH(8);
+#undef LN_BWD_LAUNCH
   float* outs[3] = {dgamma, dbeta, dbias};
   int gy = nblk / 16; if (gy > 8) gy = 8; if (gy < 1) gy = 1;
   for (int k = 0; k < 3; ++k)

@@ -282,11 +282,12 @@ class EfficientNet(nn.Module):
         lib.pool_bn_act(bs.z2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), None, bs.s.data_ptr(), B, Ho * Wo, b.mid, 1,
                         1.0 / (Ho * Wo), s)
         bs.hr = E(B, b.rd, dt=torch.float32)
+        bs.hs = E(B, b.rd, dt=torch.float32)
         bs.gate = E(B, b.mid, dt=torch.float32)
         bs.weT = E(b.rd, b.mid, dt=torch.float32)
         lib.se_mlp_fwd(bs.s.data_ptr(), V(n + ".se.conv_reduce.weight").data_ptr(), V(n + ".se.conv_reduce.bias").data_ptr(),
                        V(n + ".se.conv_expand.weight").data_ptr(), V(n + ".se.conv_expand.bias").data_ptr(),
-                       bs.weT.data_ptr(), bs.hr.data_ptr(), bs.gate.data_ptr(), B, b.mid, b.rd, s)
+                       bs.weT.data_ptr(), bs.hr.data_ptr(), bs.hs.data_ptr(), bs.gate.data_ptr(), B, b.mid, b.rd, s)
         pw = n + (".conv_pw" if b.type == "ds" else ".conv_pwl")
         bs.z3 = E(P_out, b.cout)
         w3 = SV(pw + ".weight", (b.cout, b.mid))
@@ -381,7 +382,7 @@ class EfficientNet(nn.Module):
         lib.pool_bn_act(bs.z2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), da2g.data_ptr(), dgate.data_ptr(), B, Ho * Wo, b.mid,
                         1, 1.0, s)
         dr, ds, dweT = E(B, b.rd, dt=torch.float32), E(B, b.mid, dt=torch.float32), E(b.rd, b.mid, dt=torch.float32)
-        lib.se_mlp_bwd(dgate.data_ptr(), bs.gate.data_ptr(), bs.hr.data_ptr(), bs.s.data_ptr(),
+        lib.se_mlp_bwd(dgate.data_ptr(), bs.gate.data_ptr(), bs.hr.data_ptr(), bs.hs.data_ptr(), bs.s.data_ptr(),
                        V(n + ".se.conv_reduce.weight").data_ptr(), bs.weT.data_ptr(),
                        dr.data_ptr(), ds.data_ptr(), dweT.data_ptr(), G(n + ".se.conv_reduce.weight").data_ptr(),
                        G(n + ".se.conv_reduce.bias").data_ptr(), G(n + ".se.conv_expand.weight").data_ptr(),

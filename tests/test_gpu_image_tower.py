@@ -140,20 +140,21 @@ def test_batchnorm_stats_apply_backward(C, P):
 
 def test_squeeze_excite_mlp():
     lib, s = _lib()
-    B, C, RD = 11, 144, 6
+    B, C, RD = 11, 144, 20
     sq = rnd(B, C, seed=1).requires_grad_(True)
     Wr, br = rnd(RD, C, seed=2, scale=0.2).requires_grad_(True), rnd(RD, seed=3, scale=0.2).requires_grad_(True)
     We, be = rnd(C, RD, seed=4, scale=0.2).requires_grad_(True), rnd(C, seed=5, scale=0.2).requires_grad_(True)
     hr, gate, weT = torch.empty(B, RD, device=DEV), torch.empty(B, C, device=DEV), torch.empty(RD, C, device=DEV)
+    hs = torch.empty(B, RD, device=DEV)
     lib.se_mlp_fwd(sq.data_ptr(), Wr.data_ptr(), br.data_ptr(), We.data_ptr(), be.data_ptr(), weT.data_ptr(), hr.data_ptr(),
-                   gate.data_ptr(), B, C, RD, s)
+                   hs.data_ptr(), gate.data_ptr(), B, C, RD, s)
     ref = torch.sigmoid(F.linear(F.silu(F.linear(sq, Wr, br)), We, be))
     assert torch.allclose(gate, ref, atol=1e-5)
     dgate = rnd(B, C, seed=6)
     ref.backward(dgate)
     dr, ds, dweT = torch.empty(B, RD, device=DEV), torch.empty(B, C, device=DEV), torch.empty(RD, C, device=DEV)
     gs = [torch.zeros_like(t) for t in (Wr, br, We, be)]
-    lib.se_mlp_bwd(dgate.data_ptr(), gate.data_ptr(), hr.data_ptr(), sq.data_ptr(), Wr.data_ptr(), weT.data_ptr(), dr.data_ptr(),
+    lib.se_mlp_bwd(dgate.data_ptr(), gate.data_ptr(), hr.data_ptr(), hs.data_ptr(), sq.data_ptr(), Wr.data_ptr(), weT.data_ptr(), dr.data_ptr(),
                    ds.data_ptr(), dweT.data_ptr(), gs[0].data_ptr(), gs[1].data_ptr(), gs[2].data_ptr(), gs[3].data_ptr(), B, C, RD, s)
     assert torch.allclose(ds, sq.grad, rtol=1e-4, atol=1e-6)
     for g, t in zip(gs, (Wr, br, We, be)):
