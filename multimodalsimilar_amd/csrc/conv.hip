@@ -13,6 +13,7 @@
 // Pointwise (1x1) convs are GEMMs over [pixels, channels] (gemm.hip), optionally with the BN+SiLU+gate
 // transform fused into the operand load.
 #include "common.h"
+#include <stdlib.h>
 
 struct CgMap { int G, nr, cg, rl; bool active; };
 __device__ __forceinline__ CgMap cg_map(int C) {
@@ -386,10 +387,12 @@ struct DwGeom { int B, Hi, Wi, Ho, Wo, C; };
 
 // forward: a [B,Hi,Wi,C] -> z [B,Ho,Wo,C]; fused per-channel sum / sumsq of z (bf16-rounded) for the next BN.
 // thread = (octet, strip of TW output pixels along W)
-template <int K, int S>
+// V = 0: one kernel row at a time (few registers);  V = 1: all K x NIN input chunks of an item are requested up front and
+// kept PACKED (bf16) until used, so a thread has K x NIN 16-byte loads in flight instead of NIN (latency-bound otherwise)
+template <int K, int S, int TW, int V>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* __restrict__ a, const float* __restrict__ wT, bf16* z, float* parts, DwGeom g,
                                                          int items_per_block) {
-  constexpr int TW = 4, PAD = K / 2, NIN = (TW - 1) * S + K;
+  constexpr int PAD = K / 2, NIN = (TW - 1) * S + K;
   __shared__ float lds[256 * 16];
   const CgMap m = cg_map(g.C);
   float st[16];
@@ -407,28 +410,93 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* __restrict_
       for (int j = 0; j < TW; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
-#pragma unroll 1
-      for (int kh = 0; kh < K; ++kh) {
-        const int hi = ho * S - PAD + kh;
-        if (hi < 0 || hi >= g.Hi) continue;
-        float in[NIN][8];
+      if constexpr (V == 2) {            // batches of up to 3 kernel rows in flight (K = 5: 3 + 2), packed
 #pragma unroll
-        for (int x = 0; x < NIN; ++x) {
-          const int wi = wo0 * S - PAD + x;
-          if (wi >= 0 && wi < g.Wi)
-            unpack8(*reinterpret_cast<const uint4*>(a + (((size_t)b * g.Hi + hi) * g.Wi + wi) * g.C + m.cg * 8), in[x]);
-          else
+        for (int kh0 = 0; kh0 < K; kh0 += 3) {
+          constexpr int RB = 3;
+          uint4 pk[RB][NIN];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) in[x][e] = 0.f;
+          for (int r = 0; r < RB; ++r) {
+            const int kh = kh0 + r;
+            const int hi = ho * S - PAD + kh;
+#pragma unroll
+            for (int x = 0; x < NIN; ++x) {
+              const int wi = wo0 * S - PAD + x;
+              pk[r][x] = (kh < K && hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi)
+                             ? *reinterpret_cast<const uint4*>(a + (((size_t)b * g.Hi + hi) * g.Wi + wi) * g.C + m.cg * 8)
+                             : make_uint4(0, 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < RB; ++r) {
+            const int kh = kh0 + r;
+            if (kh >= K) break;
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+              float w[8];
+              ld8f(wT + (size_t)(kh * K + kw) * g.C + m.cg * 8, w);
+#pragma unroll
+              for (int j = 0; j < TW; ++j) {
+                float in[8];
+                unpack8(pk[r][j * S + kw], in);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[j][e] += in[e] * w[e];
+              }
+            }
+          }
+        }
+      } else if constexpr (V == 1) {
+        uint4 pk[K][NIN];
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+          const int hi = ho * S - PAD + kh;
+#pragma unroll
+          for (int x = 0; x < NIN; ++x) {
+            const int wi = wo0 * S - PAD + x;
+            pk[kh][x] = (hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi)
+                            ? *reinterpret_cast<const uint4*>(a + (((size_t)b * g.Hi + hi) * g.Wi + wi) * g.C + m.cg * 8)
+                            : make_uint4(0, 0, 0, 0);
+          }
         }
 #pragma unroll
-        for (int kw = 0; kw < K; ++kw) {
-          float w[8];
-          ld8f(wT + (size_t)(kh * K + kw) * g.C + m.cg * 8, w);
+        for (int kh = 0; kh < K; ++kh) {
 #pragma unroll
-          for (int j = 0; j < TW; ++j)
+          for (int kw = 0; kw < K; ++kw) {
+            float w[8];
+            ld8f(wT + (size_t)(kh * K + kw) * g.C + m.cg * 8, w);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[j][e] += in[j * S + kw][e] * w[e];
+            for (int j = 0; j < TW; ++j) {
+              float in[8];
+              unpack8(pk[kh][j * S + kw], in);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[j][e] += in[e] * w[e];
+            }
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int kh = 0; kh < K; ++kh) {
+          const int hi = ho * S - PAD + kh;
+          if (hi < 0 || hi >= g.Hi) continue;
+          float in[NIN][8];
+#pragma unroll
+          for (int x = 0; x < NIN; ++x) {
+            const int wi = wo0 * S - PAD + x;
+            if (wi >= 0 && wi < g.Wi)
+              unpack8(*reinterpret_cast<const uint4*>(a + (((size_t)b * g.Hi + hi) * g.Wi + wi) * g.C + m.cg * 8), in[x]);
+            else
+#pragma unroll
+              for (int e = 0; e < 8; ++e) in[x][e] = 0.f;
+          }
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            float w[8];
+            ld8f(wT + (size_t)(kh * K + kw) * g.C + m.cg * 8, w);
+#pragma unroll
+            for (int j = 0; j < TW; ++j)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[j][e] += in[j * S + kw][e] * w[e];
+          }
         }
       }
 #pragma unroll
@@ -480,6 +548,36 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const bf16* dz, co
         // stride 1: a correlation with the flipped kernel.  One dz row segment (TW + K - 1 chunks) is loaded per kernel
         // row and reused by all K taps of all TW outputs from registers.
         constexpr int NIN = TW + K - 1;
+        if constexpr (K == 3) {
+          // all K x NIN chunks requested up front and kept packed: K*NIN loads in flight per thread (see dwconv_fwd V = 1)
+          uint4 pk[K][NIN];
+#pragma unroll
+          for (int kh = 0; kh < K; ++kh) {
+            const int ho = hi + PAD - kh;
+#pragma unroll
+            for (int x = 0; x < NIN; ++x) {
+              const int wo = wi0 - PAD + x;
+              pk[kh][x] = (ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo)
+                              ? *reinterpret_cast<const uint4*>(dz + (((size_t)b * g.Ho + ho) * g.Wo + wo) * g.C + c0)
+                              : make_uint4(0, 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int kh = 0; kh < K; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+              float w[8];
+              ld8f(wT + (size_t)(kh * K + kw) * g.C + c0, w);
+#pragma unroll
+              for (int j = 0; j < TW; ++j) {
+                float in[8];
+                unpack8(pk[kh][j + K - 1 - kw], in);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[j][e] += in[e] * w[e];
+              }
+            }
+          }
+        } else {
 #pragma unroll 1
         for (int kh = 0; kh < K; ++kh) {
           const int ho = hi + PAD - kh;
@@ -503,6 +601,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const bf16* dz, co
 #pragma unroll
               for (int e = 0; e < 8; ++e) acc[j][e] += in[j + K - 1 - kw][e] * w[e];
           }
+        }
         }
       } else {
 #pragma unroll
@@ -919,11 +1018,22 @@ extern "C" int mmsim_dwconv_fwd(const void* a, const float* w_tap_major, void* z
                                 int S, float* scratch, unsigned long long scratch_floats, void* stream) {
   DwGeom g; int rc = dw_check(B, Hi, Wi, C, K, S, &g); if (rc) return rc;
   MMSIM_REQUIRE(a && w_tap_major && z && sums, "dwconv_fwd: null operand");
+  // V (see the kernel): packed up-front loads pay for 3x3 (2x faster, 72-96 VGPRs of loads in flight); 5x5 would need 160
+  // and is best served by the row-at-a-time form.  MMSIM_DW_VARIANT=0/1/2 forces one form (tools/bench_dw.py).
+  static int variant = -2;
+  if (variant == -2) { const char* e = getenv("MMSIM_DW_VARIANT"); variant = e ? atoi(e) % 10 : -1; }
+  const int Vv = variant >= 0 ? variant : (K == 3 ? 1 : 0);
   const int nitems = B * g.Ho * ((g.Wo + 3) / 4);
   const int ipb = rows_per_block_for(nitems, nr_of(C));
   dim3 grid((nitems + ipb - 1) / ipb, cg_grid_y(C));
   REQ_SCRATCH((size_t)grid.x * 2 * C, "dwconv_fwd");
-  DW_DISPATCH(dwconv_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)a, w_tap_major, (bf16*)z, scratch, g, ipb)
+#define DWF(KK, SS, TT, VV) hipLaunchKernelGGL((dwconv_fwd_kernel<KK, SS, TT, VV>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)a, w_tap_major, (bf16*)z, scratch, g, ipb)
+#define DWF_KS(TT, VV)                                        \
+  if (K == 3 && S == 1) DWF(3, 1, TT, VV); else if (K == 3 && S == 2) DWF(3, 2, TT, VV); \
+  else if (K == 5 && S == 1) DWF(5, 1, TT, VV); else DWF(5, 2, TT, VV);
+  if (Vv == 1) { DWF_KS(4, 1) } else if (Vv == 2) { DWF_KS(4, 2) } else { DWF_KS(4, 0) }
+#undef DWF_KS
+#undef DWF
   launch_reduce(scratch, grid.x, 2 * C, sums, 0, (hipStream_t)stream);
   return mmsim_check_launch("dwconv_fwd");
 }
