@@ -9,7 +9,7 @@ training step, BASELINE.json's metric, on synthetic inputs resident in HBM.
 One step = forward (both towers, normalise+concat, fused ArcFace margin + cross-entropy) + backward + gradient
 all-reduce (N > 1) + both fused AdamW updates + LR schedules: nothing is skipped or cached inside the timed region.
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline     - the dominant kernel (the bf16 MFMA GEMM gemm_fast256_kernel<false,true>, Y = X W^T): algorithmic
+  roofline     - the dominant kernel (the bf16 MFMA GEMM gemm_pp64_kernel<false,true,256>, Y = X W^T): algorithmic
                  FLOPs (2 M N K per launch) / its mean launch duration measured with HIP events on the launch stream
                  over the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak (MI355X_MICROARCH.md);
   cpu_baseline - the oracle's CPU restatement of the same step (oracle/step_ref.py, kind "port") on the host cores,
@@ -39,8 +39,8 @@ def algorithmic_flops_per_pair(cfg):
         f += 3 * L * (24 * S * H * H + 4 * S * S * H)
         D = H
     if cfg["kind"] in ("cv", "multimodal"):
-        from oracle import effnet_ref
-        macs, _ = effnet_ref.count_macs_params(cfg["image"], cfg["res"])
+        from multimodalsimilar_amd.effnet import count_macs
+        macs = count_macs(cfg["image"], cfg["res"])
         f += 3 * 2 * macs
         D = (cfg.get("fc_dim", 0) if cfg.get("use_fc") else {"efficientnet_b0": 1280, "efficientnet_b4": 1792}[cfg["image"]]) + \
             (D if cfg["kind"] == "multimodal" else 0)
@@ -48,16 +48,16 @@ def algorithmic_flops_per_pair(cfg):
     return f
 
 
-def _goes_to_fast256_nt(a, b, c, trans_a, b_kmajor, kw):
-    """Mirror of the dispatch in csrc/gemm_fast.hip: forward-layout launches that run gemm_fast256_kernel<false,true>."""
+def _goes_to_pp64_nt(a, b, c, trans_a, b_kmajor, kw):
+    """Mirror of the dispatch in csrc/gemm_fast.hip: forward-layout launches that run gemm_pp64_kernel<false,true,256>."""
     if trans_a or not b_kmajor or kw.get("split_k", 1) != 1:
         return False
     M, N, K = c.shape[0], c.shape[1], a.shape[1]
-    return M % 256 == 0 and N % 256 == 0 and K % 32 == 0 and (M // 256) * (N // 256) >= 128 and c.stride(0) % 4 == 0
+    return M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and (M // 256) * (N // 256) >= 128 and c.stride(0) % 4 == 0
 
 
 class GemmTimer:
-    """HIP events around every launch of the dominant kernel, gemm_fast256_kernel<false,true> (Y = X W^T), on the
+    """HIP events around every launch of the dominant kernel, gemm_pp64_kernel<false,true,256> (Y = X W^T), on the
     launch stream (torch's current stream is the stream the C ABI launches on)."""
 
     def __init__(self, ops):
@@ -65,7 +65,7 @@ class GemmTimer:
 
     def install(self):
         def timed(a, b, c, *, trans_a=False, b_kmajor=True, **kw):
-            if not self.on or not _goes_to_fast256_nt(a, b, c, trans_a, b_kmajor, kw):
+            if not self.on or not _goes_to_pp64_nt(a, b, c, trans_a, b_kmajor, kw):
                 return self.orig(a, b, c, trans_a=trans_a, b_kmajor=b_kmajor, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -218,7 +218,7 @@ def main():
                        "step_mfma_frac": (fpp * cfg["batch"] / (ms * 1e-3) / 1e12) / MFMA_BF16_PEAK_TFLOPS,
                        "final_loss": lossv},
             "roofline": None if g is None else {
-                "bound": "mfma", "kernel": "gemm_fast256_kernel<false,true,256> (Y = X W^T: 256x256x32 tiles, LDS-DMA ring, bf16 MFMA 16x16x32, fp32 accumulate)",
+                "bound": "mfma", "kernel": "gemm_pp64_kernel<false,true,256> (Y = X W^T: 256x256 tiles, 64-deep LDS-DMA slices, ping-pong wave groups, bf16 MFMA 16x16x32, fp32 accumulate)",
                 "achieved": g["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": None, "launches": g["launches"], "avg_launch_us": g["avg_us"]},
         }

@@ -301,6 +301,15 @@ __global__ __launch_bounds__(512, 2) void gemm_fast256_kernel(GemmParams p) {
 #undef GEMM256_STEP
   const bool fs = split == 0;
   float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
+  if (p.dbg & 8) {                  // ablation: keep the accumulators live but skip the staged epilogue
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sacc == 12345.678f) reinterpret_cast<float*>(p.C)[0] = sacc;
+    return;
+  }
 #pragma unroll
   for (int half = 0; half < MT / 4; ++half) {
     __syncthreads();          // ring (first pass) / previous staging pass fully consumed
@@ -315,75 +324,19 @@ __global__ __launch_bounds__(512, 2) void gemm_fast256_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Persistent form of the pipelined kernel: one workgroup per CU walks its share of the (split, tile) list, and the
-// LDS-DMA prologue of tile k+1 (four K-slices) is issued BEFORE the epilogue of tile k, so the epilogue's stores and
-// the next tile's first loads overlap instead of each tile paying prologue latency + epilogue tail back to back
-// (at K = 1024 those were ~40 % of a tile's time).  The epilogue is staged through a small per-wave LDS region that
-// sits BESIDE the operand ring (16 rows x 64 fp32 per wave, XOR-swizzled 16-B slots: conflict-free both ways), one
-// 16-row MFMA tile row at a time, and leaves as whole 128-B / 256-B row segments.
-template <int EPI, int CMODE>
-__device__ __forceinline__ void chunk_epilogue(const GemmParams& p, const f4 (&a)[4], int row0, int col0, int lane,
-                                               bool first_split, float* stg) {
-  const int r = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) *reinterpret_cast<f4*>(stg + r * 64 + (((j * 4 + g) ^ r) << 2)) = a[j];
-  if (CMODE == 3) {
-#pragma unroll 4
-    for (int rr = 0; rr < 16; ++rr)
-      atomicAdd(reinterpret_cast<float*>(p.C) + (size_t)(row0 + rr) * p.ldc + col0 + lane,
-                stg[rr * 64 + ((((lane >> 2) ^ rr) << 2) | (lane & 3))] * p.alpha);
-    return;
-  }
-  const int c4 = lane & 15, n = col0 + c4 * 4;
-  const bool add_bias = (p.bias != nullptr) && first_split;
-  const float4 bias = add_bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int rr = it * 4 + g;
-    const size_t m = (size_t)(row0 + rr);
-    const f4 x = *reinterpret_cast<const f4*>(stg + rr * 64 + ((c4 ^ rr) << 2));
-    float v[4] = {x[0] * p.alpha + bias.x, x[1] * p.alpha + bias.y, x[2] * p.alpha + bias.z, x[3] * p.alpha + bias.w};
-    if (EPI == EPI_GELU) {
-      bf4 pre = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-      *reinterpret_cast<bf4*>(p.aux_out + m * p.ld_aux + n) = pre;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = gelu_f(bf2f(pre[e]));
-    } else if (EPI == EPI_MUL_GELU_GRAD) {
-      const bf4 y = *reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(bf2f(y[e]));
-    } else if (EPI == EPI_ADD) {
-      const bf4 y = *reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += bf2f(y[e]);
-    } else if (EPI == EPI_TANH) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
-    }
-    if (CMODE == 0) {
-      bf4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-      *reinterpret_cast<bf4*>(reinterpret_cast<bf16*>(p.C) + m * p.ldc + n) = o;
-    } else {
-      float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
-      if (CMODE == 1) {
-        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        const float4 old = *reinterpret_cast<const float4*>(c);
-        *reinterpret_cast<float4*>(c) = make_float4(v[0] + old.x, v[1] + old.y, v[2] + old.z, v[3] + old.w);
-      }
-    }
-  }
-}
-
-template <int MT, int EPI, int CMODE>
-__device__ __forceinline__ void tile_epilogue(const GemmParams& p, f4 (&acc)[MT][4], int row0, int col0, int lane, bool fs,
-                                              float* stg) {
-#pragma unroll
-  for (int i = 0; i < MT; ++i) chunk_epilogue<EPI, CMODE>(p, acc[i], row0 + i * 16, col0, lane, fs, stg);
-}
-
+// Ping-pong form of the 256 x BN x 32 kernel.  The eight waves are two groups of four (waves w and w+4 share a SIMD);
+// every K-step of a wave is  [barrier] LOAD phase: fragments of slice t from LDS -> registers, LDS-DMA of slice t+3,
+// counted waits  [barrier] COMPUTE phase: 32 MFMAs at raised priority.  Group 1 executes one extra barrier before its
+// loop, so the groups run in anti-phase: while one wave of a SIMD issues its MFMAs back to back, its partner issues
+// DMA descriptors and LDS reads -- in the single-barrier form above both waves of a SIMD reach their ~500-cycle
+// load section together and the matrix pipe idles through it (measured: DMA+reads alone and MFMA alone each took as
+// long as 70 % of the full loop).  One fragment set suffices (the partner's MFMAs, not this wave's, hide the reads).
+//   RAW: every wave waits (vmcnt) for slice t+1 at the END of load phase t, i.e. before a barrier that every reader of
+//        slice t+1 passes before its load phase t+1 (group 0: B1(t+1) = group 1's B2(t); group 1: B1(t+1) = group 0's B2(t+1)).
+//   WAR: slice t+3 goes to the slot of slice t-1, whose reads every wave retired (lgkmcnt(0)) before ITS B2(t-1); a
+//        group-0 wave issues after B1(t) (= group 1's B2(t-1)), a group-1 wave after its B1(t) (= group 0's B2(t)).
 template <bool TA, bool TB_KMAJOR, int BN>
-__global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmParams p) {
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   constexpr int MT = BN == 256 ? 8 : 4;
   constexpr int WROWS = MT * 16;
   constexpr int A_BYTES = GBM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
@@ -392,119 +345,236 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = BN == 256 ? (wave >> 2) : (wave >> 1), wn = BN == 256 ? (wave & 3) : (wave & 1);
-  float* stg = reinterpret_cast<float*>(smem + G_SLOTS * STAGE) + wave * (16 * 64);
+  const int grp = wave >> 2;
 
-  // this block's share of the (split, tile) list: XCD x owns one contiguous chunk, its blocks interleave inside it
   const int ntiles = p.tiles_m * p.tiles_n;
   const int nwg = ntiles * p.splits;
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-  const int q8 = nwg >> 3, r8 = nwg & 7;
-  const int cstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-  const int cend = cstart + q8 + (xcd < r8 ? 1 : 0);
-  int w = cstart + idx;
-  if (w >= cend) return;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int split = wg / ntiles, tile = wg - split * ntiles;
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const int m0 = tm * GBM, n0 = tn * BN;
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg) / GBK;
 
-  int split, m0, n0, kbeg, nk;
-  auto decode = [&](int wg, int& sp, int& mm, int& nn, int& kb, int& nks) {
-    sp = wg / ntiles;
-    const int tile = wg - sp * ntiles;
-    mm = (tile / p.tiles_n) * GBM; nn = (tile % p.tiles_n) * BN;
-    kb = sp * p.k_per_split;
-    nks = (min(p.K, kb + p.k_per_split) - kb) / GBK;
-  };
-  auto prologue = [&](int mm, int nn, int kb, int nks) {
+  f4 acc[MT][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (t < nks) {
-        dma_tile32<TA, GBM>(p.A, p.lda, mm, kb + t * GBK, smem + t * STAGE, wave, lane);
-        dma_tile32<!TB_KMAJOR, BN>(p.B, p.ldb, nn, kb + t * GBK, smem + t * STAGE + A_BYTES, wave, lane);
-      }
-  };
-  decode(w, split, m0, n0, kbeg, nk);
-  prologue(m0, n0, kbeg, nk);
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-  while (true) {
-    f4 acc[MT][4];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+    if (t < nk && !(p.dbg & 1)) {
+      dma_tile32<TA, GBM>(p.A, p.lda, m0, kbeg + t * GBK, smem + t * STAGE, wave, lane);
+      dma_tile32<!TB_KMAJOR, BN>(p.B, p.ldb, n0, kbeg + t * GBK, smem + t * STAGE + A_BYTES, wave, lane);
+    }
+  {
+    const int ahead = min(nk - 1, 2);                    // slices issued after slice 0
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (grp == 1) __builtin_amdgcn_s_barrier();            // the anti-phase offset
+  bf8 af[MT], bfr[4];
+  for (int t = 0; t < nk; ++t) {
+    __builtin_amdgcn_s_barrier();                        // B1
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const char* la = smem + (t & 3) * STAGE;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = gfrag<!TB_KMAJOR, BN>(la + A_BYTES, wn * 64 + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = gfrag<TA, GBM>(la, wm * WROWS + i * 16, lane);
+    }
+    if (t + 3 < nk && !(p.dbg & 1)) {
+      char* ns = smem + ((t + 3) & 3) * STAGE;
+      dma_tile32<TA, GBM>(p.A, p.lda, m0, kbeg + (t + 3) * GBK, ns, wave, lane);
+      dma_tile32<!TB_KMAJOR, BN>(p.B, p.ldb, n0, kbeg + (t + 3) * GBK, ns + A_BYTES, wave, lane);
+    }
+    {
+      const int ahead = min(nk - 1, t + 3) - (t + 1);   // slices that may stay in flight behind slice t+1
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // B2
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(p.dbg & 4)) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();            // both groups have now executed 2 nk + 1 barriers
+  const bool fs = split == 0;
+  float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
+  if (p.dbg & 8) {
+    float sacc = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
-    bf8 afA[MT], bfA[4], afB[MT], bfB[4];
-    {
-      const int ahead = min(nk - 1, 3);
-      if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
-      else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfA[j] = gfrag<!TB_KMAJOR, BN>(smem + A_BYTES, wn * 64 + j * 16, lane);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) afA[i] = gfrag<TA, GBM>(smem, wm * WROWS + i * 16, lane);
-    }
-#define GEMMP_STEP(af0, bf0, af1, bf1, T)                                                                           \
-  {                                                                                                                 \
-    const int t_ = (T);                                                                                             \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    if (t_ + 1 < nk) {                                                                                              \
-      const int ahead = min(nk - 2 - t_, 2);                                                                        \
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");                                \
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");                               \
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
-      __builtin_amdgcn_s_barrier();                                                                                 \
-      __builtin_amdgcn_sched_barrier(0);                                                                            \
-      if (t_ + 4 < nk) {                                                                                            \
-        char* ns = smem + (t_ & 3) * STAGE;                                                                         \
-        dma_tile32<TA, GBM>(p.A, p.lda, m0, kbeg + (t_ + 4) * GBK, ns, wave, lane);                                 \
-        dma_tile32<!TB_KMAJOR, BN>(p.B, p.ldb, n0, kbeg + (t_ + 4) * GBK, ns + A_BYTES, wave, lane);                \
-      }                                                                                                             \
-      const char* la = smem + ((t_ + 1) & 3) * STAGE;                                                               \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) bf1[j] = gfrag<!TB_KMAJOR, BN>(la + A_BYTES, wn * 64 + j * 16, lane); \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i) af1[i] = gfrag<TA, GBM>(la, wm * WROWS + i * 16, lane);        \
-    }                                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                  \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j], af0[i], acc[i][j], 0, 0, 0);                    \
+      for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sacc == 12345.678f) reinterpret_cast<float*>(p.C)[0] = sacc;
+    return;
   }
-    for (int t = 0; t < nk; t += 2) {
-      GEMMP_STEP(afA, bfA, afB, bfB, t)
-      if (t + 1 < nk) GEMMP_STEP(afB, bfB, afA, bfA, t + 1)
-    }
-#undef GEMMP_STEP
-    // every wave has read its last fragments (lgkmcnt(0) above); after this barrier the ring may be refilled
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int half = 0; half < MT / 4; ++half) {
+    __syncthreads();
+    f4 (&a4)[4][4] = *reinterpret_cast<f4 (*)[4][4]>(&acc[half * 4][0]);
+    const int row0 = m0 + wm * WROWS + half * 64, col0 = n0 + wn * 64;
+    if (!p.c_f32) fast_epilogue_epi<0>(p, a4, row0, col0, lane, fs, stg);
+    else if (p.atomic) fast_epilogue<EPI_NONE, 3>(p, a4, row0, col0, lane, fs, stg);
+    else if (p.accum) fast_epilogue<EPI_NONE, 2>(p, a4, row0, col0, lane, fs, stg);
+    else if (p.epi == EPI_TANH) fast_epilogue<EPI_TANH, 1>(p, a4, row0, col0, lane, fs, stg);
+    else fast_epilogue<EPI_NONE, 1>(p, a4, row0, col0, lane, fs, stg);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Ping-pong kernel with 64-deep K-slices: the same anti-phase schedule, but an LDS-DMA wave-instruction now moves
+// 8 rows x 128 B (whole cache lines) instead of 16 rows x 64 B -- the texture-address path prices an instruction by the
+// lines it touches, and with 64-B pieces the DMA stream alone (no MFMA) ran at 11.5 TB/s chip-wide, slower than the
+// MFMAs it has to feed.  LDS (160 KiB, all of it): A ring 3 x 32 KiB (the streamed operand: its next slice is issued
+// three steps before it is read, enough for an HBM miss) + B ring 2 x (BN x 128 B).  A 64-deep slice is consumed in two
+// 32-deep steps (one fragment set, 32 MFMAs per wave each):
+//   even step 2u:   B1 | read k-half 0 of slice u; issue B_{u+1};                      lgkmcnt(0) | B2 | MFMAs
+//   odd  step 2u+1: B1 | read k-half 1 of slice u; issue A_{u+2}; vmcnt(|A_{u+2}|);    lgkmcnt(0) | B2 | MFMAs
+// Per-wave issue order is A0 B0 A1 | B1 A2 | B2 A3 | ..., so "all but the youngest A unit" at the end of an odd step
+// means slice u+1 (A_{u+1}, B_{u+1}) has landed.  RAW / WAR arguments as for gemm_pp_kernel: a unit is waited for at the
+// end of the load phase BEFORE the one that first reads it, and a slot is refilled in the load phase AFTER the one
+// that last read it (B_{u+1} -> slot of B_{u-1}, last read in step 2u-1; A_{u+2} -> slot of A_{u-1}, same).
+template <bool TRANS, int ROWS>
+__device__ __forceinline__ bf8 hfrag(const char* lds, int rbase, int ks, int lane) {
+  if (!TRANS) {
+    const int row = rbase + (lane & 15), kc = ks * 4 + (lane >> 4);
+    return ds_read_b128_asm(lds + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+  } else {
+    return ffrag<true, ROWS>(lds, rbase, ks, lane);
+  }
+}
+
+template <bool TA, bool TB_KMAJOR, int BN>
+__global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
+  constexpr int MT = BN == 256 ? 8 : 4;
+  constexpr int WROWS = MT * 16;
+  constexpr int A_UNIT = GBM * 128, B_UNIT = BN * 128;     // bytes per 64-deep slice of each operand
+  constexpr int A_LPU = 4;                                 // LDS-DMA instructions per wave per A unit
+  constexpr int B_OFF = 3 * A_UNIT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = BN == 256 ? (wave >> 2) : (wave >> 1), wn = BN == 256 ? (wave & 3) : (wave & 1);
+  const int grp = wave >> 2;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int nwg = ntiles * p.splits;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int split = wg / ntiles, tile = wg - split * ntiles;
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const int m0 = tm * GBM, n0 = tn * BN;
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int ns = (kend - kbeg) / 64;
+
+  f4 acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  const bool dma_on = !(p.dbg & 1);
+  if (dma_on) {
+    dma_tile<TA, GBM>(p.A, p.lda, m0, kbeg, smem, wave, lane);
+    dma_tile<!TB_KMAJOR, BN>(p.B, p.ldb, n0, kbeg, smem + B_OFF, wave, lane);
+    if (ns > 1) dma_tile<TA, GBM>(p.A, p.lda, m0, kbeg + 64, smem + A_UNIT, wave, lane);
+  }
+  if (ns > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LPU) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (grp == 1) __builtin_amdgcn_s_barrier();            // the anti-phase offset
+  bf8 af[MT], bfr[4];
+  int sa = 0;                                            // A slot of slice u (u mod 3)
+#define PP64_READ(KS)                                                                                    \
+  {                                                                                                      \
+    const char* la = smem + sa * A_UNIT;                                                                 \
+    const char* lb = smem + B_OFF + (u & 1) * B_UNIT;                                                    \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) bfr[j] = hfrag<!TB_KMAJOR, BN>(lb, wn * 64 + j * 16, KS, lane); \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) af[i] = hfrag<TA, GBM>(la, wm * WROWS + i * 16, KS, lane);     \
+  }
+#define PP64_MFMA()                                                                                      \
+  __builtin_amdgcn_s_barrier();                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                     \
+  if (!(p.dbg & 4)) {                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                       \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);          \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+  }                                                                                                      \
+  __builtin_amdgcn_sched_barrier(0);
+  for (int u = 0; u < ns; ++u) {
+    // ---- even step: k-half 0 of slice u
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    const int wn_ = w + bpx;
-    const bool has_next = wn_ < cend;
-    int split2 = 0, m2 = 0, n2 = 0, kb2 = 0, nk2 = 0;
-    if (has_next) {
-      decode(wn_, split2, m2, n2, kb2, nk2);
-      prologue(m2, n2, kb2, nk2);                 // in flight while the epilogue below runs
+    PP64_READ(0)
+    if (u + 1 < ns && dma_on)
+      dma_tile<!TB_KMAJOR, BN>(p.B, p.ldb, n0, kbeg + (u + 1) * 64, smem + B_OFF + ((u + 1) & 1) * B_UNIT, wave, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP64_MFMA()
+    // ---- odd step: k-half 1 of slice u
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    PP64_READ(1)
+    if (u + 2 < ns) {
+      int sn = sa + 2; if (sn >= 3) sn -= 3;
+      if (dma_on) dma_tile<TA, GBM>(p.A, p.lda, m0, kbeg + (u + 2) * 64, smem + sn * A_UNIT, wave, lane);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LPU) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    const bool fs = split == 0;
-    const int row0 = m0 + wm * WROWS, col0 = n0 + wn * 64;
-    if (!p.c_f32) {
-      switch (p.epi) {
-        case EPI_GELU: tile_epilogue<MT, EPI_GELU, 0>(p, acc, row0, col0, lane, fs, stg); break;
-        case EPI_MUL_GELU_GRAD: tile_epilogue<MT, EPI_MUL_GELU_GRAD, 0>(p, acc, row0, col0, lane, fs, stg); break;
-        case EPI_ADD: tile_epilogue<MT, EPI_ADD, 0>(p, acc, row0, col0, lane, fs, stg); break;
-        case EPI_TANH: tile_epilogue<MT, EPI_TANH, 0>(p, acc, row0, col0, lane, fs, stg); break;
-        default: tile_epilogue<MT, EPI_NONE, 0>(p, acc, row0, col0, lane, fs, stg); break;
-      }
-    } else if (p.atomic) tile_epilogue<MT, EPI_NONE, 3>(p, acc, row0, col0, lane, fs, stg);
-    else if (p.accum) tile_epilogue<MT, EPI_NONE, 2>(p, acc, row0, col0, lane, fs, stg);
-    else if (p.epi == EPI_TANH) tile_epilogue<MT, EPI_TANH, 1>(p, acc, row0, col0, lane, fs, stg);
-    else tile_epilogue<MT, EPI_NONE, 1>(p, acc, row0, col0, lane, fs, stg);
-    if (!has_next) break;
-    w = wn_; split = split2; m0 = m2; n0 = n2; kbeg = kb2; nk = nk2;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP64_MFMA()
+    sa = sa + 1; if (sa >= 3) sa = 0;
+  }
+#undef PP64_READ
+#undef PP64_MFMA
+  if (grp == 0) __builtin_amdgcn_s_barrier();            // both groups have now executed 4 ns + 1 barriers
+  const bool fs = split == 0;
+  float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
+  if (p.dbg & 8) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sacc == 12345.678f) reinterpret_cast<float*>(p.C)[0] = sacc;
+    return;
+  }
+#pragma unroll
+  for (int half = 0; half < MT / 4; ++half) {
+    __syncthreads();
+    f4 (&a4)[4][4] = *reinterpret_cast<f4 (*)[4][4]>(&acc[half * 4][0]);
+    const int row0 = m0 + wm * WROWS + half * 64, col0 = n0 + wn * 64;
+    if (!p.c_f32) fast_epilogue_epi<0>(p, a4, row0, col0, lane, fs, stg);
+    else if (p.atomic) fast_epilogue<EPI_NONE, 3>(p, a4, row0, col0, lane, fs, stg);
+    else if (p.accum) fast_epilogue<EPI_NONE, 2>(p, a4, row0, col0, lane, fs, stg);
+    else if (p.epi == EPI_TANH) fast_epilogue<EPI_TANH, 1>(p, a4, row0, col0, lane, fs, stg);
+    else fast_epilogue<EPI_NONE, 1>(p, a4, row0, col0, lane, fs, stg);
   }
 }
 
 static bool pipe_eligible(const GemmParams& p, int splits, int bn) {
-  if (p.M % GBM || p.N % bn || p.K % GBK || p.k_per_split % GBK) return false;
+  if (p.M % GBM || p.N % bn || p.K % 64 || p.k_per_split % 64) return false;
   return (p.M / GBM) * (p.N / bn) * splits >= 128;        // enough blocks to fill the chip
 }
 static bool fast128_eligible(const GemmParams& p, int splits) {
@@ -526,61 +596,41 @@ static int tile_pref() {      // MMSIM_GEMM_TILE: 0 auto (default), 1 = old 256x
   return v;
 }
 
-// MMSIM_GEMM_PERSIST=1 selects the persistent form.  Measured (round 1): no gain on the forward layout (the epilogue
-// is executed by the same waves, so only the ~2 us prologue latency per tile is hidden) and a loss on the layouts with
-// transposed operands, whose instantiations spill inside the K loop at 256 VGPRs; it stays opt-in until the address
-// arithmetic is moved to immediates / SGPRs (DESIGN.md "open items").
-static int persist_pref() {
+// MMSIM_GEMM_PP: 2 (default) ping-pong with 64-deep slices, 1 ping-pong with 32-deep slices, 0 the single-barrier form
+static int pp_pref() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("MMSIM_GEMM_PERSIST"); v = e ? atoi(e) : 0; }
+  if (v < 0) { const char* e = getenv("MMSIM_GEMM_PP"); v = e ? atoi(e) : 2; }
   return v;
-}
-static int num_cus() {
-  static int n = 0;
-  if (!n) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); n = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
-  return n;
-}
-
-template <int BN>
-static void launch_pers(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s) {
-  p.tiles_m = p.M / GBM; p.tiles_n = p.N / BN; p.splits = splits;
-  const int nwg = p.tiles_m * p.tiles_n * splits;
-  int nblk = (num_cus() / 8) * 8;                      // one workgroup per CU, a multiple of the 8 XCDs
-  if (nblk > ((nwg + 7) / 8) * 8) nblk = ((nwg + 7) / 8) * 8;
-  dim3 grid(nblk), block(512);
-  const size_t lds = G_SLOTS * (GBM * 64 + BN * 64) + 8 * 16 * 64 * 4;      // operand ring + per-wave epilogue staging
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<false, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<false, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<true, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<true, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    done = true;
-  }
-  if (!trans_a && b_kmajor) hipLaunchKernelGGL((gemm_pers_kernel<false, true, BN>), grid, block, lds, s, p);
-  else if (!trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_pers_kernel<false, false, BN>), grid, block, lds, s, p);
-  else if (trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_pers_kernel<true, false, BN>), grid, block, lds, s, p);
-  else hipLaunchKernelGGL((gemm_pers_kernel<true, true, BN>), grid, block, lds, s, p);
 }
 
 template <int BN>
 static void launch_pipe(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s) {
-  if (persist_pref()) { launch_pers<BN>(p, trans_a, b_kmajor, splits, s); return; }
   p.tiles_m = p.M / GBM; p.tiles_n = p.N / BN; p.splits = splits;
   dim3 grid(p.tiles_m * p.tiles_n * splits), block(512);
-  const size_t lds = 8 * 64 * EP_PITCH * 4;      // 136 KiB: epilogue staging (8 waves x 64 x 68 floats) >= the operand ring
+  // 136 KiB: epilogue staging (8 waves x 64 x 68 floats) >= the 32-deep operand rings; 160 KiB: the 64-deep rings
+  const int pp = pp_pref();
+  const size_t lds_stage = 8 * 64 * EP_PITCH * 4, lds_ring64 = 3 * GBM * 128 + 2 * BN * 128;
+  const size_t lds = (pp >= 2 && lds_ring64 > lds_stage) ? lds_ring64 : lds_stage;
   static bool done = false;
   if (!done) {
-    (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<false, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<false, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<true, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_fast256_kernel<true, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds64 = 3 * GBM * 128 + 2 * BN * 128, lds32 = 8 * 64 * EP_PITCH * 4;
+#define SET_LDS(KERNEL)                                                                                              \
+    (void)hipFuncSetAttribute((const void*)KERNEL<false, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+    (void)hipFuncSetAttribute((const void*)KERNEL<false, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    (void)hipFuncSetAttribute((const void*)KERNEL<true, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+    (void)hipFuncSetAttribute((const void*)KERNEL<true, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { const size_t lds = lds32; SET_LDS(gemm_fast256_kernel) SET_LDS(gemm_pp_kernel) }
+    { const size_t lds = lds64 > lds32 ? lds64 : lds32; SET_LDS(gemm_pp64_kernel) }
+#undef SET_LDS
     done = true;
   }
-  if (!trans_a && b_kmajor) hipLaunchKernelGGL((gemm_fast256_kernel<false, true, BN>), grid, block, lds, s, p);
-  else if (!trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_fast256_kernel<false, false, BN>), grid, block, lds, s, p);
-  else if (trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_fast256_kernel<true, false, BN>), grid, block, lds, s, p);
-  else hipLaunchKernelGGL((gemm_fast256_kernel<true, true, BN>), grid, block, lds, s, p);
+#define LAUNCH(KERNEL)                                                                                               \
+  if (!trans_a && b_kmajor) hipLaunchKernelGGL((KERNEL<false, true, BN>), grid, block, lds, s, p);                   \
+  else if (!trans_a && !b_kmajor) hipLaunchKernelGGL((KERNEL<false, false, BN>), grid, block, lds, s, p);            \
+  else if (trans_a && !b_kmajor) hipLaunchKernelGGL((KERNEL<true, false, BN>), grid, block, lds, s, p);              \
+  else hipLaunchKernelGGL((KERNEL<true, true, BN>), grid, block, lds, s, p);
+  if (pp >= 2) { LAUNCH(gemm_pp64_kernel) } else if (pp == 1) { LAUNCH(gemm_pp_kernel) } else { LAUNCH(gemm_fast256_kernel) }
+#undef LAUNCH
 }
 
 void gemm_fast_launch(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s) {

@@ -51,6 +51,20 @@ def build_arch(model_name):
     return SimpleNamespace(stem=stem, head=head, blocks=blocks, last=cin)
 
 
+def count_macs(model_name, res=224):
+    """Multiply-accumulates of one forward pass through the backbone (convolutions + SE MLPs), for bench.py's flop count."""
+    a = build_arch(model_name)
+    h = res // 2
+    macs = h * h * a.stem * 27
+    for b in a.blocks:
+        ho = h // b.stride
+        if b.type == "ir":
+            macs += h * h * b.cin * b.mid
+        macs += ho * ho * b.mid * b.k ** 2 + 2 * b.mid * b.rd + ho * ho * b.mid * b.cout
+        h = ho
+    return macs + h * h * a.last * a.head
+
+
 class _Holder(nn.Module):
     pass
 

@@ -1,11 +1,11 @@
-"""Ablation of the 256x256x32 GEMM main loop (GPU box): MMSIM_GEMM_DBG bits 1 = no DMA, 2 = no LDS reads, 4 = no MFMA."""
+"""Ablation of the 256x256x32 GEMM main loop (GPU box): MMSIM_GEMM_DBG bits 1 = no DMA, 4 = no MFMA, 8 = no epilogue."""
 import os, subprocess, sys
 code = r'''
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from multimodalsimilar_amd import ops
 M=32768
-for name,N,K,lay in (("ffn1-NT",4096,1024,"nt"),("ffn2-NT",1024,4096,"nt"),("ffn1-NN",1024,4096,"nn")):
+for name,N,K,lay in (("o-NT",1024,1024,"nt"),("ffn1-NT",4096,1024,"nt"),("ffn2-NT",1024,4096,"nt"),("ffn1-NN",1024,4096,"nn")):
     if lay=="nt":
         a=torch.randn(M,K,device="cuda").bfloat16(); b=(torch.randn(N,K,device="cuda")*0.05).bfloat16(); kw={}
     else:
@@ -20,7 +20,7 @@ for name,N,K,lay in (("ffn1-NT",4096,1024,"nt"),("ffn2-NT",1024,4096,"nt"),("ffn
     t=e0.elapsed_time(e1)/10
     print(f"  {name}: {t*1e3:8.1f} us  ({2.0*M*N*K/t/1e9:7.1f} TF-equivalent)")
 '''
-for dbg, label in ((0, "full"), (1, "no DMA"), (2, "no LDS reads"), (4, "no MFMA"), (3, "MFMA only"), (6, "DMA only"), (5, "LDS reads only")):
+for dbg, label in ((0, "full"), (8, "no epilogue"), (1, "no DMA"), (4, "no MFMA"), (9, "no DMA, no epilogue"), (12, "no MFMA, no epilogue")):
     print(f"dbg={dbg} [{label}]", flush=True)
     env = dict(os.environ, MMSIM_GEMM_DBG=str(dbg))
     subprocess.run([sys.executable, "-c", code], env=env)
