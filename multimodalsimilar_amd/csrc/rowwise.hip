@@ -302,6 +302,115 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dh_a, const bf1
   }
 }
 
+// 8 columns per lane per 512-column chunk (16-byte loads / stores) and TWO rows per wave in flight: the one-row form
+// above is latency-bound (each row is load -> two wave reductions -> store, 8 bytes per lane per stream in flight).
+template <int NC>      // NC = ceil(H / 512)
+__global__ __launch_bounds__(256) void ln_bwd8_kernel(const bf16* __restrict__ dh_a, const bf16* __restrict__ dh_b, const bf16* __restrict__ y,
+                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                      const float* __restrict__ gamma, bf16* __restrict__ dy, bf16* __restrict__ dt,
+                                                      float* parts, int M, int H, int rows_per_wave, Drop dr) {
+  __shared__ float red[3][4][64 * 8];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r0 = (blockIdx.x * 4 + wv) * rows_per_wave, r1 = min(M, r0 + rows_per_wave);
+  float ag[NC][8], ab[NC][8], abias[NC][8], gm[NC][8];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = lane * 8 + c * 512;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[c][e] = ab[c][e] = abias[c][e] = 0.f; gm[c][e] = col < H ? gamma[col + e] : 0.f; }
+  }
+  for (int row = r0; row < r1; row += 2) {
+    const bool two = row + 1 < r1;
+    float g[2][NC][8], xh[2][NC][8], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rs[2];
+    bf8 dv[2][NC], ev[2][NC], yv[2][NC];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const size_t base = (size_t)(row + (q && two ? 1 : 0)) * H;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int col = lane * 8 + c * 512;
+        if (col < H) {
+          dv[q][c] = *reinterpret_cast<const bf8*>(dh_a + base + col);
+          if (dh_b) ev[q][c] = *reinterpret_cast<const bf8*>(dh_b + base + col);
+          yv[q][c] = *reinterpret_cast<const bf8*>(y + base + col);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int rr = row + (q && two ? 1 : 0);
+      const float mean = mean_i[rr];
+      rs[q] = rstd_i[rr];
+      const bool live = q == 0 || two;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int col = lane * 8 + c * 512;
+        if (col < H) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float d = bf2f(dv[q][c][e]);
+            if (dh_b) d += bf2f(ev[q][c][e]);
+            if (!live) d = 0.f;
+            const float x = (bf2f(yv[q][c][e]) - mean) * rs[q];
+            xh[q][c][e] = x;
+            ag[c][e] += d * x; ab[c][e] += d;
+            const float gg = d * gm[c][e];
+            g[q][c][e] = gg;
+            s1[q] += gg; s2[q] += gg * x;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {       // the four row sums reduce together: one shuffle latency chain, not four
+      s1[0] += __shfl_xor(s1[0], o, 64); s2[0] += __shfl_xor(s2[0], o, 64);
+      s1[1] += __shfl_xor(s1[1], o, 64); s2[1] += __shfl_xor(s2[1], o, 64);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (q == 1 && !two) break;
+      const size_t base = (size_t)(row + q) * H;
+      const float m1 = s1[q] / H, m2 = s2[q] / H;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int col = lane * 8 + c * 512;
+        if (col < H) {
+          float o[8];
+          bf8 ob;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { o[e] = rs[q] * (g[q][c][e] - m1 - xh[q][c][e] * m2); ob[e] = f2bf(o[e]); }
+          *reinterpret_cast<bf8*>(dy + base + col) = ob;
+          if (dr.thresh) {
+            const float4 a = drop4(make_float4(o[0], o[1], o[2], o[3]), dr, (unsigned long long)base + col);
+            const float4 b = drop4(make_float4(o[4], o[5], o[6], o[7]), dr, (unsigned long long)base + col + 4);
+            ob[0] = f2bf(a.x); ob[1] = f2bf(a.y); ob[2] = f2bf(a.z); ob[3] = f2bf(a.w);
+            ob[4] = f2bf(b.x); ob[5] = f2bf(b.y); ob[6] = f2bf(b.z); ob[7] = f2bf(b.w);
+            *reinterpret_cast<bf8*>(dt + base + col) = ob;
+          }
+          // the dense-output gradient the GEMMs consume is the bf16-rounded value
+#pragma unroll
+          for (int e = 0; e < 8; ++e) abias[c][e] += bf2f(ob[e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = lane * 8 + c * 512;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][wv][lane * 8 + e] = ag[c][e]; red[1][wv][lane * 8 + e] = ab[c][e]; red[2][wv][lane * 8 + e] = abias[c][e]; }
+    __syncthreads();
+    if (wv < 3 && col < H) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = lane * 8 + e;
+        parts[((size_t)blockIdx.x * 3 + wv) * H + col + e] = (red[wv][0][i] + red[wv][1][i]) + (red[wv][2][i] + red[wv][3][i]);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- column sums of a bf16 matrix
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* x, int ld, float* out, int M, int N, int rows_per_block) {
   __shared__ float red[4][64 * 8];
@@ -435,9 +544,18 @@ extern "C" int mmsim_ln_bwd(const void* dh_a, const void* dh_b, const void* y, c
   hipLaunchKernelGGL((ln_bwd_kernel<NCV>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16*)dh_a, (const bf16*)dh_b, \
                      (const bf16*)y, mean, rstd, gamma, (bf16*)dy, (bf16*)dt, scratch, M, H, rpw,                  \
                      make_drop(dropout_p, seed, stream_id))
+  if (H % 8 == 0 && H <= 1024) {
+#define LN_BWD8_LAUNCH(NCV)                                                                                          \
+  hipLaunchKernelGGL((ln_bwd8_kernel<NCV>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16*)dh_a, (const bf16*)dh_b, \
+                     (const bf16*)y, mean, rstd, gamma, (bf16*)dy, (bf16*)dt, scratch, M, H, rpw,                  \
+                     make_drop(dropout_p, seed, stream_id))
+    if (H <= 512) LN_BWD8_LAUNCH(1); else LN_BWD8_LAUNCH(2);
+#undef LN_BWD8_LAUNCH
+  } else {
   const int nc = (H + 255) / 256;
   if (nc <= 1) LN_BWD_LAUNCH(1); else if (nc == 2) LN_BWD_LAUNCH(2); else if (nc == 3) LN_BWD_LAUNCH(3);
   else if (nc == 4) LN_BWD_LAUNCH(4); else LN_BWD_LAUNCH(8);
+  }
 #undef LN_BWD_LAUNCH
   float* outs[3] = {dgamma, dbeta, dbias};
   int gy = nblk / 16; if (gy > 8) gy = 8; if (gy < 1) gy = 1;

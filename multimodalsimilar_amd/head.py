@@ -103,7 +103,11 @@ class ArcMarginProduct(nn.Module):
         dxh = self._buf("dxh", (B, D), torch.float32)
         dwh = self._buf("dwh", (C, D), torch.float32)
         dx = torch.empty((B, D), dtype=torch.float32, device=dcos.device)
-        ops.gemm(dcos[:, :C], st["wh"], dxh, b_kmajor=False)                         # dxh = dcos @ Wh
+        # dxh = dcos @ Wh: 2 x 22 output tiles over a 100k-long reduction -> split-K (fp32 atomics into the zeroed buffer)
+        sk = ops.pick_split_k(B, D, C)
+        if sk > 1:
+            dxh.zero_()
+        ops.gemm(dcos[:, :C], st["wh"], dxh, b_kmajor=False, split_k=sk, accumulate=sk > 1)
         ops.gemm(dcos[:, :C], st["xh"], dwh, trans_a=True, b_kmajor=False)           # dWh = dcos^T @ xh
         ops.l2norm_bwd(st["x"], st["inv_x"], dxh, 0, dx)
         ops.l2norm_bwd(self.weight.detach(), st["inv_w"], dwh, 0, self._flat.gview("weight"), accumulate=True)
