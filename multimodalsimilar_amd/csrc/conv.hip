@@ -15,6 +15,12 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef DW_BD_PACKED
+#define DW_BD_PACKED 0   // backward-data 3x3: 1 = all 3 x 6 chunks requested up front (packed), 0 = one kernel row at a time
+#endif
+#ifndef DW_WAVES
+#define DW_WAVES 2      // min waves per SIMD asked of the depthwise kernels (2: cap at 256 VGPRs, 4: 128)
+#endif
 struct CgMap { int G, nr, cg, rl; bool active; };
 __device__ __forceinline__ CgMap cg_map(int C) {
   CgMap m;
@@ -56,6 +62,14 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   for (int e = 0; e < 8; ++e) b[e] = f2bf(f[e]);
   return __builtin_bit_cast(uint4, b);
 }
+// Bounds-masked 16-byte load: the ADDRESS is always valid (callers clamp the coordinates) and the value is zeroed
+// afterwards.  Writing `ok ? *p : 0` instead makes hipcc branch around every load and wait vmcnt(0) per element --
+// the loads of a row then complete one L2 round trip after the other (cdna_hip_programming.md section 5, trap 4c).
+__device__ __forceinline__ uint4 ld16_masked(const bf16* p, bool ok) {
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
   f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
@@ -390,7 +404,7 @@ struct DwGeom { int B, Hi, Wi, Ho, Wo, C; };
 // V = 0: one kernel row at a time (few registers);  V = 1: all K x NIN input chunks of an item are requested up front and
 // kept PACKED (bf16) until used, so a thread has K x NIN 16-byte loads in flight instead of NIN (latency-bound otherwise)
 template <int K, int S, int TW, int V>
-__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* __restrict__ a, const float* __restrict__ wT, bf16* z, float* parts, DwGeom g,
+__global__ __launch_bounds__(256, DW_WAVES) void dwconv_fwd_kernel(const bf16* __restrict__ a, const float* __restrict__ wT, bf16* z, float* parts, DwGeom g,
                                                          int items_per_block) {
   constexpr int PAD = K / 2, NIN = (TW - 1) * S + K;
   __shared__ float lds[256 * 16];
@@ -422,9 +436,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* __restrict_
 #pragma unroll
             for (int x = 0; x < NIN; ++x) {
               const int wi = wo0 * S - PAD + x;
-              pk[r][x] = (kh < K && hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi)
-                             ? *reinterpret_cast<const uint4*>(a + (((size_t)b * g.Hi + hi) * g.Wi + wi) * g.C + m.cg * 8)
-                             : make_uint4(0, 0, 0, 0);
+              pk[r][x] = ld16_masked(a + (((size_t)b * g.Hi + clampi(hi, 0, g.Hi - 1)) * g.Wi + clampi(wi, 0, g.Wi - 1)) * g.C + m.cg * 8,
+                                     kh < K && hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi);
             }
           }
 #pragma unroll
@@ -453,9 +466,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* __restrict_
 #pragma unroll
           for (int x = 0; x < NIN; ++x) {
             const int wi = wo0 * S - PAD + x;
-            pk[kh][x] = (hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi)
-                            ? *reinterpret_cast<const uint4*>(a + (((size_t)b * g.Hi + hi) * g.Wi + wi) * g.C + m.cg * 8)
-                            : make_uint4(0, 0, 0, 0);
+            pk[kh][x] = ld16_masked(a + (((size_t)b * g.Hi + clampi(hi, 0, g.Hi - 1)) * g.Wi + clampi(wi, 0, g.Wi - 1)) * g.C + m.cg * 8,
+                                    hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi);
           }
         }
 #pragma unroll
@@ -477,17 +489,17 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* __restrict_
 #pragma unroll 1
         for (int kh = 0; kh < K; ++kh) {
           const int hi = ho * S - PAD + kh;
-          if (hi < 0 || hi >= g.Hi) continue;
-          float in[NIN][8];
+          const bool hv = hi >= 0 && hi < g.Hi;
+          const bf16* arow = a + ((size_t)b * g.Hi + clampi(hi, 0, g.Hi - 1)) * g.Wi * g.C + m.cg * 8;
+          uint4 raw[NIN];
 #pragma unroll
           for (int x = 0; x < NIN; ++x) {
             const int wi = wo0 * S - PAD + x;
-            if (wi >= 0 && wi < g.Wi)
-              unpack8(*reinterpret_cast<const uint4*>(a + (((size_t)b * g.Hi + hi) * g.Wi + wi) * g.C + m.cg * 8), in[x]);
-            else
-#pragma unroll
-              for (int e = 0; e < 8; ++e) in[x][e] = 0.f;
+            raw[x] = ld16_masked(arow + (size_t)clampi(wi, 0, g.Wi - 1) * g.C, hv && wi >= 0 && wi < g.Wi);
           }
+          float in[NIN][8];
+#pragma unroll
+          for (int x = 0; x < NIN; ++x) unpack8(raw[x], in[x]);
 #pragma unroll
           for (int kw = 0; kw < K; ++kw) {
             float w[8];
@@ -519,7 +531,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* __restrict_
 // fused: dpre = da * silu'(scale*z1+shift) written to `out`, and BN-backward sums (sum dpre, sum dpre*zhat) of the
 // producer's BatchNorm accumulated per channel.  thread = (octet, strip of TW input pixels along W)
 template <int K, int S>
-__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const bf16* dz, const float* wT, const bf16* z1, const float* mean,
+__global__ __launch_bounds__(256, DW_WAVES) void dwconv_bwd_data_kernel(const bf16* dz, const float* wT, const bf16* z1, const float* mean,
                                                               const float* rstd, const float* scale, const float* shift,
                                                               const bf16* resid, bf16* out, float* parts, DwGeom g,
                                                               int items_per_block) {
@@ -548,7 +560,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const bf16* dz, co
         // stride 1: a correlation with the flipped kernel.  One dz row segment (TW + K - 1 chunks) is loaded per kernel
         // row and reused by all K taps of all TW outputs from registers.
         constexpr int NIN = TW + K - 1;
-        if constexpr (K == 3) {
+        if constexpr (K == 3 && DW_BD_PACKED) {
           // all K x NIN chunks requested up front and kept packed: K*NIN loads in flight per thread (see dwconv_fwd V = 1)
           uint4 pk[K][NIN];
 #pragma unroll
@@ -557,9 +569,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const bf16* dz, co
 #pragma unroll
             for (int x = 0; x < NIN; ++x) {
               const int wo = wi0 - PAD + x;
-              pk[kh][x] = (ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo)
-                              ? *reinterpret_cast<const uint4*>(dz + (((size_t)b * g.Ho + ho) * g.Wo + wo) * g.C + c0)
-                              : make_uint4(0, 0, 0, 0);
+              pk[kh][x] = ld16_masked(dz + (((size_t)b * g.Ho + clampi(ho, 0, g.Ho - 1)) * g.Wo + clampi(wo, 0, g.Wo - 1)) * g.C + c0,
+                                      ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo);
             }
           }
 #pragma unroll
@@ -581,17 +592,17 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const bf16* dz, co
 #pragma unroll 1
         for (int kh = 0; kh < K; ++kh) {
           const int ho = hi + PAD - kh;
-          if (ho < 0 || ho >= g.Ho) continue;
-          float in[NIN][8];
+          const bool hv = ho >= 0 && ho < g.Ho;
+          const bf16* drow = dz + ((size_t)b * g.Ho + clampi(ho, 0, g.Ho - 1)) * g.Wo * g.C + c0;
+          uint4 raw[NIN];
 #pragma unroll
           for (int x = 0; x < NIN; ++x) {
             const int wo = wi0 - PAD + x;
-            if (wo >= 0 && wo < g.Wo)
-              unpack8(*reinterpret_cast<const uint4*>(dz + (((size_t)b * g.Ho + ho) * g.Wo + wo) * g.C + c0), in[x]);
-            else
-#pragma unroll
-              for (int e = 0; e < 8; ++e) in[x][e] = 0.f;
+            raw[x] = ld16_masked(drow + (size_t)clampi(wo, 0, g.Wo - 1) * g.C, hv && wo >= 0 && wo < g.Wo);
           }
+          float in[NIN][8];
+#pragma unroll
+          for (int x = 0; x < NIN; ++x) unpack8(raw[x], in[x]);
 #pragma unroll
           for (int kw = 0; kw < K; ++kw) {
             float w[8];
@@ -604,27 +615,29 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const bf16* dz, co
         }
         }
       } else {
+      // stride 2: only kernel rows with hi + PAD - kh even reach a dz row, and within such a row the strip's four
+      // pixels touch the 4 consecutive dz columns wi0/2 - 1 .. wi0/2 + 2 (wi0 is a multiple of 4): one masked 4-chunk
+      // segment per row, tap parity resolved at compile time.
+#pragma unroll 1
+      for (int kh = (hi + PAD) & 1; kh < K; kh += 2) {
+        const int ho = (hi + PAD - kh) >> 1;
+        const bool hv = ho >= 0 && ho < g.Ho;
+        const bf16* drow = dz + ((size_t)b * g.Ho + clampi(ho, 0, g.Ho - 1)) * g.Wo * g.C + c0;
+        const int wb = (wi0 >> 1) - 1;
+        float seg[4][8];
 #pragma unroll
-      for (int kh = 0; kh < K; ++kh) {
-        const int t = hi + PAD - kh;
-        if (t < 0 || (t % S) != 0) continue;
-        const int ho = t / S;
-        if (ho >= g.Ho) continue;
+        for (int q = 0; q < 4; ++q)
+          unpack8(ld16_masked(drow + (size_t)clampi(wb + q, 0, g.Wo - 1) * g.C, hv && wb + q >= 0 && wb + q < g.Wo), seg[q]);
 #pragma unroll
-        for (int j = 0; j < TW; ++j) {
+        for (int kw = 0; kw < K; ++kw) {
+          float w[8];
+          ld8f(wT + (size_t)(kh * K + kw) * g.C + c0, w);
 #pragma unroll
-          for (int kw = 0; kw < K; ++kw) {
-            // wi0 is a multiple of TW (and so of S): divisibility of (wi0 + j + PAD - kw) by S is a compile-time fact
-            if (((j + PAD - kw) % S + S) % S != 0) continue;
-            const int u = wi0 + j + PAD - kw;
-            if (u < 0) continue;
-            const int wo = u / S;
-            if (wo >= g.Wo) continue;
-            float d[8], w[8];
-            unpack8(*reinterpret_cast<const uint4*>(dz + (((size_t)b * g.Ho + ho) * g.Wo + wo) * g.C + c0), d);
-            ld8f(wT + (size_t)(kh * K + kw) * g.C + c0, w);
+          for (int j = 0; j < TW; ++j) {
+            if (((j + PAD - kw) & 1) != 0) continue;         // compile-time after unrolling
+            const int q = (j + PAD - kw + 4) / 2 - 1;         // = (j + PAD - kw) / 2 + 1 for the even values -2 .. 4
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[j][e] += d[e] * w[e];
+            for (int e = 0; e < 8; ++e) acc[j][e] += seg[q][e] * w[e];
           }
         }
       }
@@ -683,47 +696,28 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16* __re
       if (hi < 0 || hi >= g.Hi) continue;
       const bf16* arow = a + (((size_t)b * g.Hi + hi) * g.Wi) * g.C + c0;
       const bf16* drow = dz + (((size_t)b * g.Ho + ho) * g.Wo) * g.C + c0;
-      if constexpr (S == 1) {
-        // sliding window over the input row: one new input chunk + one dz chunk per output pixel (instead of K + 1)
-        float win[K][8];
+      // strips of 4 output pixels: 4 dz chunks + (3 S + K) input chunks requested together (bounds-masked, no branches)
+      constexpr int NIN = 3 * S + K;
+      for (int w0 = 0; w0 < g.Wo; w0 += 4) {
+        uint4 dr[4], ar[NIN];
 #pragma unroll
-        for (int x = 0; x < K - 1; ++x) {
-          const int wi = x - PAD;
-          if (wi >= 0 && wi < g.Wi) unpack8(*reinterpret_cast<const uint4*>(arow + (size_t)wi * g.C), win[x + 1]);
-          else
+        for (int j = 0; j < 4; ++j) dr[j] = ld16_masked(drow + (size_t)min(w0 + j, g.Wo - 1) * g.C, w0 + j < g.Wo);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) win[x + 1][e] = 0.f;
+        for (int x = 0; x < NIN; ++x) {
+          const int wi = w0 * S - PAD + x;
+          ar[x] = ld16_masked(arow + (size_t)clampi(wi, 0, g.Wi - 1) * g.C, wi >= 0 && wi < g.Wi);
         }
-        for (int wo = 0; wo < g.Wo; ++wo) {
+        float xin[NIN][8];
 #pragma unroll
-          for (int x = 0; x < K - 1; ++x)
+        for (int x = 0; x < NIN; ++x) unpack8(ar[x], xin[x]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) win[x][e] = win[x + 1][e];
-          const int wi = wo + K - 1 - PAD;
-          if (wi < g.Wi) unpack8(*reinterpret_cast<const uint4*>(arow + (size_t)wi * g.C), win[K - 1]);
-          else
-#pragma unroll
-            for (int e = 0; e < 8; ++e) win[K - 1][e] = 0.f;
+        for (int j = 0; j < 4; ++j) {
           float d[8];
-          unpack8(*reinterpret_cast<const uint4*>(drow + (size_t)wo * g.C), d);
+          unpack8(dr[j], d);
 #pragma unroll
           for (int kw = 0; kw < K; ++kw)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[kw * 8 + e] += d[e] * win[kw][e];
-        }
-      } else {
-        for (int wo = 0; wo < g.Wo; ++wo) {
-          float d[8];
-          unpack8(*reinterpret_cast<const uint4*>(drow + (size_t)wo * g.C), d);
-#pragma unroll
-          for (int kw = 0; kw < K; ++kw) {
-            const int wi = wo * S - PAD + kw;
-            if (wi < 0 || wi >= g.Wi) continue;
-            float x[8];
-            unpack8(*reinterpret_cast<const uint4*>(arow + (size_t)wi * g.C), x);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[kw * 8 + e] += d[e] * x[e];
-          }
+            for (int e = 0; e < 8; ++e) acc[kw * 8 + e] += d[e] * xin[j * S + kw][e];
         }
       }
     }
