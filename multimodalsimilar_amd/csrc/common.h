@@ -49,7 +49,9 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of an IEEE division: `1.0f / y` expands to the ~10-instruction div_scale / fma / div_fixup
+// sequence, which made every SiLU-carrying kernel (and the GEMM operand transform) VALU-bound
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 __device__ __forceinline__ float silu_grad_f(float x) {
   const float s = sigmoid_f(x);

@@ -67,7 +67,8 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 // the loads of a row then complete one L2 round trip after the other (cdna_hip_programming.md section 5, trap 4c).
 __device__ __forceinline__ uint4 ld16_masked(const bf16* p, bool ok) {
   const uint4 v = *reinterpret_cast<const uint4*>(p);
-  return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+  const unsigned int msk = ok ? 0xffffffffu : 0u;          // AND, not select: hipcc turns select-of-load back into a branch
+  return make_uint4(v.x & msk, v.y & msk, v.z & msk, v.w & msk);
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
@@ -746,22 +747,27 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
       float acc[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+      // all 27 image taps requested together, bounds-masked (clamped address, value zeroed): no per-load branches
+      float v[27];
 #pragma unroll
       for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
           const int hi = ho * 2 - 1 + kh;
-          if (hi < 0 || hi >= g.Hi) continue;
+          const float* xrow = x + (((size_t)b * 3 + ci) * g.Hi + clampi(hi, 0, g.Hi - 1)) * g.Wi;
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
             const int wi = wo * 2 - 1 + kw;
-            if (wi < 0 || wi >= g.Wi) continue;
-            const float v = x[(((size_t)b * 3 + ci) * g.Hi + hi) * g.Wi + wi];
-            const float* wp = wl + (ci * 9 + kh * 3 + kw) * g.Co + c0;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += v * wp[e];
+            const unsigned int t = reinterpret_cast<const unsigned int*>(xrow)[clampi(wi, 0, g.Wi - 1)];
+            v[ci * 9 + kh * 3 + kw] = __uint_as_float(t & ((hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi) ? 0xffffffffu : 0u));
           }
         }
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        const float* wp = wl + t * g.Co + c0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[t] * wp[e];
+      }
       const uint4 o = pack8(acc);
       *reinterpret_cast<uint4*>(z + (size_t)p * g.Co + c0) = o;
       float r[8];
@@ -773,11 +779,14 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
   block_reduce_store<16>(st, m, lds, parts + (size_t)blockIdx.x * 2 * g.Co, (size_t)g.Co);
 }
 
-// dW[co][ci][kh][kw] += sum_p dz[p,co] * x[p @ tap]; thread = (tap, octet), loops over the block's pixel slab
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16* dz, const float* x, float* dw, StemGeom g, int pix_per_block) {
-  const int G = g.Co >> 3;
-  const int t = threadIdx.x;
-  if (t >= 27 * G) return;
+// dW[co][ci][kh][kw] += sum_p dz[p,co] * x[p @ tap]; thread = (pixel lane, tap, octet): SW_LANES pixel lanes share a
+// block's pixel slab (a single lane is latency-bound: 2 k trips of dependent round trips), reduced through LDS at the end
+#define SW_LANES 4
+__global__ __launch_bounds__(27 * 8 * SW_LANES) void stem_wgrad_kernel(const bf16* dz, const float* x, float* dw, StemGeom g, int pix_per_block) {
+  __shared__ float red[SW_LANES][27 * 8 * 8];
+  const int G = g.Co >> 3, per = 27 * G;
+  const int pl = threadIdx.x / per, t = threadIdx.x - pl * per;
+  const bool active = pl < SW_LANES;
   const int tap = t / G, cg = t % G, c0 = cg * 8;
   const int ci = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
   float acc[8];
@@ -785,18 +794,41 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16* dz, const f
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
   const int npix = g.B * g.Ho * g.Wo;
   const int p0 = blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
-  for (int p = p0; p < p1; ++p) {
-    const int wo = p % g.Wo, ho = (p / g.Wo) % g.Ho, b = p / (g.Wo * g.Ho);
-    const int hi = ho * 2 - 1 + kh, wi = wo * 2 - 1 + kw;
-    if (hi < 0 || hi >= g.Hi || wi < 0 || wi >= g.Wi) continue;
-    const float v = x[(((size_t)b * 3 + ci) * g.Hi + hi) * g.Wi + wi];
-    float d[8];
-    unpack8(*reinterpret_cast<const uint4*>(dz + (size_t)p * g.Co + c0), d);
+  if (active)
+  for (int pb = p0 + pl * 8; pb < p1; pb += 8 * SW_LANES) {         // 8 pixels per trip: 8 + 8 independent (bounds-masked) loads in flight
+    float v[8];
+    uint4 dr[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] += v * d[e];
+    for (int q = 0; q < 8; ++q) {
+      const int p = min(pb + q, p1 - 1);
+      const int wo = p % g.Wo, ho = (p / g.Wo) % g.Ho, b = p / (g.Wo * g.Ho);
+      const int hi = ho * 2 - 1 + kh, wi = wo * 2 - 1 + kw;
+      const unsigned int t2 = reinterpret_cast<const unsigned int*>(x)[(((size_t)b * 3 + ci) * g.Hi + clampi(hi, 0, g.Hi - 1)) * g.Wi + clampi(wi, 0, g.Wi - 1)];
+      v[q] = __uint_as_float(t2 & ((pb + q < p1 && hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi) ? 0xffffffffu : 0u));
+      dr[q] = *reinterpret_cast<const uint4*>(dz + (size_t)p * g.Co + c0);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float d[8];
+      unpack8(dr[q], d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[q] * d[e];
+    }
   }
+  if (active) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) atomicAdd(dw + (size_t)(c0 + e) * 27 + tap, acc[e]);
+    for (int e = 0; e < 8; ++e) red[pl][t * 8 + e] = acc[e];
+  }
+  __syncthreads();
+  if (active && pl == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float sum = 0.f;
+#pragma unroll
+      for (int l = 0; l < SW_LANES; ++l) sum += red[l][t * 8 + e];
+      atomicAdd(dw + (size_t)(c0 + e) * 27 + tap, sum);
+    }
+  }
 }
 
 // ------------------------------------------------------------------ BatchNorm1d on fp32 [B, C] (thread per channel)
@@ -1079,11 +1111,11 @@ extern "C" int mmsim_stem_fwd(const float* x, const float* w, void* z, float* su
 
 extern "C" int mmsim_stem_wgrad(const void* dz, const float* x, float* dw, int B, int Hi, int Wi, int Co, void* stream) {
   MMSIM_REQUIRE(dz && x && dw && B > 0, "stem_wgrad: bad arguments"); REQ_C8(Co, "stem_wgrad");
-  MMSIM_REQUIRE(27 * (Co / 8) <= 256, "stem_wgrad: at most 72 output channels");
+  MMSIM_REQUIRE(Co <= 64, "stem_wgrad: at most 64 output channels");
   StemGeom g; g.B = B; g.Hi = Hi; g.Wi = Wi; g.Ho = (Hi + 2 - 3) / 2 + 1; g.Wo = (Wi + 2 - 3) / 2 + 1; g.Co = Co;
   const int npix = B * g.Ho * g.Wo;
   const int ppb = 2048;
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3((npix + ppb - 1) / ppb), dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, x, dw, g, ppb);
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3((npix + ppb - 1) / ppb), dim3(27 * (Co / 8) * SW_LANES), 0, (hipStream_t)stream, (const bf16*)dz, x, dw, g, ppb);
   return mmsim_check_launch("stem_wgrad");
 }
 

@@ -26,23 +26,31 @@
 
 __device__ __forceinline__ int tr_key(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
+// Ragged tiles are handled by clamping the ADDRESS into the operand and AND-masking the VALUE: `if (in range) v = load`
+// makes hipcc branch around each of the 8 loads of a K-step and wait vmcnt(0) after every one (the loads then complete
+// one L2 round trip after the other).
 template <bool TRANS>
 __device__ __forceinline__ void load_tile(const bf16* __restrict__ X, int ld, int r0, int R, int k0, int kend,
                                           int tid, uint4 (&reg)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = tid + 256 * i;
-    uint4 v = make_uint4(0, 0, 0, 0);
+    const bf16* src;
+    bool ok;
     if (!TRANS) {
       const int row = c >> 3, kc = c & 7;
       const int gr = r0 + row, gk = k0 + kc * 8;
-      if (gr < R && gk < kend) v = *reinterpret_cast<const uint4*>(X + (size_t)gr * ld + gk);
+      ok = gr < R && gk < kend;
+      src = X + (size_t)min(gr, R - 1) * ld + (gk < kend ? gk : k0);
     } else {
       const int krow = c >> 4, rc = c & 15;
       const int gk = k0 + krow, gr = r0 + rc * 8;
-      if (gk < kend && gr < R) v = *reinterpret_cast<const uint4*>(X + (size_t)gk * ld + gr);
+      ok = gk < kend && gr < R;
+      src = X + (size_t)min(gk, kend - 1) * ld + (gr < R ? gr : r0);
     }
-    reg[i] = v;
+    const uint4 v = *reinterpret_cast<const uint4*>(src);
+    const unsigned int msk = ok ? 0xffffffffu : 0u;
+    reg[i] = make_uint4(v.x & msk, v.y & msk, v.z & msk, v.w & msk);
   }
 }
 
@@ -71,16 +79,15 @@ __device__ __forceinline__ void xform_tile(const GemmParams& p, int r0, int R, i
     const int c = tid + 256 * i;
     int pix, ch;
     bool ok;
-    if (!TRANS) { pix = r0 + (c >> 3); ch = k0 + (c & 7) * 8; ok = pix < R && ch < kend; }
-    else { pix = k0 + (c >> 4); ch = r0 + (c & 15) * 8; ok = pix < kend && ch < R; }
-    if (!ok) continue;
+    if (!TRANS) { pix = r0 + (c >> 3); ch = k0 + (c & 7) * 8; ok = pix < R && ch < kend; if (pix >= R) pix = R - 1; if (ch >= kend) ch = k0; }
+    else { pix = k0 + (c >> 4); ch = r0 + (c & 15) * 8; ok = pix < kend && ch < R; if (pix >= kend) pix = kend - 1; if (ch >= R) ch = r0; }
     const bf8 v = __builtin_bit_cast(bf8, reg[i]);
     const float4 s0 = *reinterpret_cast<const float4*>(p.xf_scale + ch), s1 = *reinterpret_cast<const float4*>(p.xf_scale + ch + 4);
     const float4 h0 = *reinterpret_cast<const float4*>(p.xf_shift + ch), h1 = *reinterpret_cast<const float4*>(p.xf_shift + ch + 4);
     const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
     const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
     float g[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-    if (p.xf_gate) {
+    if (p.xf_gate) {                     // launch-uniform
       const float* gp = p.xf_gate + (size_t)(pix / p.xf_hw) * p.xf_C + ch;
       const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
       g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
@@ -88,7 +95,9 @@ __device__ __forceinline__ void xform_tile(const GemmParams& p, int r0, int R, i
     bf8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = f2bf(silu_f(bf2f(v[e]) * sc[e] + sh[e]) * g[e]);
-    reg[i] = __builtin_bit_cast(uint4, o);
+    const uint4 ov = __builtin_bit_cast(uint4, o);
+    const unsigned int msk = ok ? 0xffffffffu : 0u;      // out-of-range elements must stay zero (silu(shift) != 0)
+    reg[i] = make_uint4(ov.x & msk, ov.y & msk, ov.z & msk, ov.w & msk);
   }
 }
 
