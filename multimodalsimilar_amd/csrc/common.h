@@ -28,6 +28,23 @@ int mmsim_check_launch(const char* what);
     }                                            \
   } while (0)
 
+// Division of an index (< 2^31) by a launch constant: one v_mul_hi + shift instead of the ~35-instruction integer
+// division sequence (the per-item  it % nstrip, it / nstrip % H, ...  decompositions cost as much as the arithmetic).
+struct FastDiv { unsigned int mul, shr, d; };
+static inline FastDiv make_fastdiv(unsigned int d) {
+  FastDiv f; f.d = d; f.mul = 0; f.shr = 0;
+  if (d > 1) {
+    unsigned int l = 0;
+    while ((1ull << l) < d) ++l;
+    const unsigned int pw = 31 + l;
+    f.mul = (unsigned int)(((1ull << pw) + d - 1) / d);
+    f.shr = pw - 32;
+  }
+  return f;
+}
+__device__ __forceinline__ unsigned int fdiv(unsigned int n, const FastDiv& f) { return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shr); }
+__device__ __forceinline__ void fdivmod(unsigned int n, const FastDiv& f, int& q, int& r) { q = (int)fdiv(n, f); r = (int)(n - (unsigned int)q * f.d); }
+
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
 

@@ -18,9 +18,9 @@
 #ifndef DW_BD_PACKED
 #define DW_BD_PACKED 0   // backward-data 3x3: 1 = all 3 x 6 chunks requested up front (packed), 0 = one kernel row at a time
 #endif
-#ifndef DW_WAVES
-#define DW_WAVES 2      // min waves per SIMD asked of the depthwise kernels (2: cap at 256 VGPRs, 4: 128)
-#endif
+// Exactly two waves per SIMD for the depthwise kernels: with a higher occupancy target hipcc's scheduler saves registers
+// by re-using one destination for consecutive loads (load, wait, load, wait ...), which serialises a row's L2 round trips.
+#define DW_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
 struct CgMap { int G, nr, cg, rl; bool active; };
 __device__ __forceinline__ CgMap cg_map(int C) {
   CgMap m;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64) void se_wgrad_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------ BN (+SiLU, +SE gate) backward
 struct BnBwd {
   const bf16* dy; const bf16* z; const float* mean; const float* rstd; const float* scale; const float* shift;
-  const float* gate; const float* dsq; int hw; int act; int P; int C; float inv_hw;
+  const float* gate; const float* dsq; int hw; int act; int P; int C; float inv_hw; FastDiv d_hw;
 };
 // da = (gate ? dy*g + dsq/HW : dy) * (act ? silu'(scale*z+shift) : 1)
 __device__ __forceinline__ void bn_bwd_elem(const BnBwd& p, int r, int c0, float (&da)[8], float (&zh)[8]) {
@@ -331,7 +331,7 @@ __device__ __forceinline__ void bn_bwd_elem(const BnBwd& p, int r, int c0, float
   unpack8(*reinterpret_cast<const uint4*>(p.z + off), z);
   ld8f(p.mean + c0, mu); ld8f(p.rstd + c0, rs);
   if (p.gate) {
-    const int b = r / p.hw;
+    const int b = (int)fdiv((unsigned int)r, p.d_hw);
     float g[8], q[8];
     ld8f(p.gate + (size_t)b * p.C + c0, g); ld8f(p.dsq + (size_t)b * p.C + c0, q);
 #pragma unroll
@@ -398,14 +398,14 @@ __global__ void dw_grad_from_tap_major_kernel(const float* gT, float* g, int C, 
   if (i < C * KK) { const int c = i / KK, t = i % KK; g[i] += gT[(size_t)t * C + c]; }
 }
 
-struct DwGeom { int B, Hi, Wi, Ho, Wo, C; };
+struct DwGeom { int B, Hi, Wi, Ho, Wo, C; FastDiv d_strip, d_rows; };   // d_strip / d_rows: strips per row, rows per image of the item space
 
 // forward: a [B,Hi,Wi,C] -> z [B,Ho,Wo,C]; fused per-channel sum / sumsq of z (bf16-rounded) for the next BN.
 // thread = (octet, strip of TW output pixels along W)
 // V = 0: one kernel row at a time (few registers);  V = 1: all K x NIN input chunks of an item are requested up front and
 // kept PACKED (bf16) until used, so a thread has K x NIN 16-byte loads in flight instead of NIN (latency-bound otherwise)
 template <int K, int S, int TW, int V>
-__global__ __launch_bounds__(256, DW_WAVES) void dwconv_fwd_kernel(const bf16* __restrict__ a, const float* __restrict__ wT, bf16* z, float* parts, DwGeom g,
+__global__ __launch_bounds__(256) DW_OCC void dwconv_fwd_kernel(const bf16* __restrict__ a, const float* __restrict__ wT, bf16* z, float* parts, DwGeom g,
                                                          int items_per_block) {
   constexpr int PAD = K / 2, NIN = (TW - 1) * S + K;
   __shared__ float lds[256 * 16];
@@ -418,7 +418,9 @@ __global__ __launch_bounds__(256, DW_WAVES) void dwconv_fwd_kernel(const bf16* _
   if (m.active) {
     const int i0 = blockIdx.x * items_per_block, i1 = min(nitems, i0 + items_per_block);
     for (int it = i0 + m.rl; it < i1; it += m.nr) {
-      const int strip = it % nstrip, ho = (it / nstrip) % g.Ho, b = it / (nstrip * g.Ho);
+      int strip, ho, b, rowi;
+      fdivmod((unsigned int)it, g.d_strip, rowi, strip);
+      fdivmod((unsigned int)rowi, g.d_rows, b, ho);
       const int wo0 = strip * TW;
       float acc[TW][8];
 #pragma unroll
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(256, DW_WAVES) void dwconv_fwd_kernel(const bf16* _
 // fused: dpre = da * silu'(scale*z1+shift) written to `out`, and BN-backward sums (sum dpre, sum dpre*zhat) of the
 // producer's BatchNorm accumulated per channel.  thread = (octet, strip of TW input pixels along W)
 template <int K, int S>
-__global__ __launch_bounds__(256, DW_WAVES) void dwconv_bwd_data_kernel(const bf16* dz, const float* wT, const bf16* z1, const float* mean,
+__global__ __launch_bounds__(256) DW_OCC void dwconv_bwd_data_kernel(const bf16* dz, const float* wT, const bf16* z1, const float* mean,
                                                               const float* rstd, const float* scale, const float* shift,
                                                               const bf16* resid, bf16* out, float* parts, DwGeom g,
                                                               int items_per_block) {
@@ -550,7 +552,9 @@ __global__ __launch_bounds__(256, DW_WAVES) void dwconv_bwd_data_kernel(const bf
     if (z1) { ld8f(mean + c0, mu); ld8f(rstd + c0, rs); ld8f(scale + c0, sc); ld8f(shift + c0, sh); }
     const int i0 = blockIdx.x * items_per_block, i1 = min(nitems, i0 + items_per_block);
     for (int it = i0 + m.rl; it < i1; it += m.nr) {
-      const int strip = it % nstrip, hi = (it / nstrip) % g.Hi, b = it / (nstrip * g.Hi);
+      int strip, hi, b, rowi;
+      fdivmod((unsigned int)it, g.d_strip, rowi, strip);
+      fdivmod((unsigned int)rowi, g.d_rows, b, hi);
       const int wi0 = strip * TW;
       float acc[TW][8];
 #pragma unroll
@@ -643,14 +647,22 @@ __global__ __launch_bounds__(256, DW_WAVES) void dwconv_bwd_data_kernel(const bf
         }
       }
       }
+      // epilogue operands (z1 or the residual gradient) of all four pixels requested together, bounds-masked
+      const bf16* eptr = z1 ? z1 : resid;
+      uint4 er[TW];
+      const size_t off0 = (((size_t)b * g.Hi + hi) * g.Wi) * g.C + c0;
+      if (eptr) {
+#pragma unroll
+        for (int j = 0; j < TW; ++j) er[j] = ld16_masked(eptr + off0 + (size_t)min(wi0 + j, g.Wi - 1) * g.C, wi0 + j < g.Wi);
+      }
 #pragma unroll
       for (int j = 0; j < TW; ++j) {
         if (wi0 + j < g.Wi) {
-          const size_t off = (((size_t)b * g.Hi + hi) * g.Wi + wi0 + j) * g.C + c0;
+          const size_t off = off0 + (size_t)(wi0 + j) * g.C;
           float o[8];
           if (z1) {
             float zz[8];
-            unpack8(*reinterpret_cast<const uint4*>(z1 + off), zz);
+            unpack8(er[j], zz);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = acc[j][e] * silu_grad_f(zz[e] * sc[e] + sh[e]);
             const uint4 pk = pack8(o);
@@ -663,7 +675,7 @@ __global__ __launch_bounds__(256, DW_WAVES) void dwconv_bwd_data_kernel(const bf
             for (int e = 0; e < 8; ++e) o[e] = acc[j][e];
             if (resid) {
               float r[8];
-              unpack8(*reinterpret_cast<const uint4*>(resid + off), r);
+              unpack8(er[j], r);
 #pragma unroll
               for (int e = 0; e < 8; ++e) o[e] += r[e];
             }
@@ -727,7 +739,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16* __re
 }
 
 // ------------------------------------------------------------------ stem conv 3x3 s2 p1 on the NCHW fp32 image
-struct StemGeom { int B, Hi, Wi, Ho, Wo, Co; };
+struct StemGeom { int B, Hi, Wi, Ho, Wo, Co; FastDiv d_wo, d_ho; };
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, bf16* z, float* parts, StemGeom g,
                                                        int pix_per_block) {
   __shared__ float lds[256 * 16];
@@ -743,7 +755,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     const int c0 = m.cg * 8;
     const int p0 = blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
     for (int p = p0 + m.rl; p < p1; p += m.nr) {
-      const int wo = p % g.Wo, ho = (p / g.Wo) % g.Ho, b = p / (g.Wo * g.Ho);
+      int wo, ho, b, rowi;
+      fdivmod((unsigned int)p, g.d_wo, rowi, wo);
+      fdivmod((unsigned int)rowi, g.d_ho, b, ho);
       float acc[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -801,7 +815,9 @@ __global__ __launch_bounds__(27 * 8 * SW_LANES) void stem_wgrad_kernel(const bf1
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int p = min(pb + q, p1 - 1);
-      const int wo = p % g.Wo, ho = (p / g.Wo) % g.Ho, b = p / (g.Wo * g.Ho);
+      int wo, ho, b, rowi;
+      fdivmod((unsigned int)p, g.d_wo, rowi, wo);
+      fdivmod((unsigned int)rowi, g.d_ho, b, ho);
       const int hi = ho * 2 - 1 + kh, wi = wo * 2 - 1 + kw;
       const unsigned int t2 = reinterpret_cast<const unsigned int*>(x)[(((size_t)b * 3 + ci) * g.Hi + clampi(hi, 0, g.Hi - 1)) * g.Wi + clampi(wi, 0, g.Wi - 1)];
       v[q] = __uint_as_float(t2 & ((pb + q < p1 && hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi) ? 0xffffffffu : 0u));
@@ -994,7 +1010,7 @@ static BnBwd mk_bnbwd(const void* dy, const void* z, const float* mean, const fl
                       const float* gate, const float* dsq, int hw, int act, int P, int C) {
   BnBwd p;
   p.dy = (const bf16*)dy; p.z = (const bf16*)z; p.mean = mean; p.rstd = rstd; p.scale = scale; p.shift = shift;
-  p.gate = gate; p.dsq = dsq; p.hw = hw > 0 ? hw : 1; p.act = act; p.P = P; p.C = C; p.inv_hw = 1.0f / (float)(hw > 0 ? hw : 1);
+  p.gate = gate; p.dsq = dsq; p.hw = hw > 0 ? hw : 1; p.act = act; p.P = P; p.C = C; p.inv_hw = 1.0f / (float)(hw > 0 ? hw : 1); p.d_hw = make_fastdiv(hw > 0 ? hw : 1);
   return p;
 }
 
@@ -1049,6 +1065,7 @@ extern "C" int mmsim_dwconv_fwd(const void* a, const float* w_tap_major, void* z
   static int variant = -2;
   if (variant == -2) { const char* e = getenv("MMSIM_DW_VARIANT"); variant = e ? atoi(e) % 10 : -1; }
   const int Vv = variant >= 0 ? variant : (K == 3 ? 1 : 0);
+  g.d_strip = make_fastdiv((g.Wo + 3) / 4); g.d_rows = make_fastdiv(g.Ho);
   const int nitems = B * g.Ho * ((g.Wo + 3) / 4);
   const int ipb = rows_per_block_for(nitems, nr_of(C));
   dim3 grid((nitems + ipb - 1) / ipb, cg_grid_y(C));
@@ -1072,6 +1089,7 @@ extern "C" int mmsim_dwconv_bwd_data(const void* dz, const float* w_tap_major, c
   MMSIM_REQUIRE(dz && w_tap_major && dpre, "dwconv_bwd_data: null operand");
   MMSIM_REQUIRE(!z1 || (mean && rstd && scale && shift && sums), "dwconv_bwd_data: fused BN+SiLU backward needs the BN state");
   MMSIM_REQUIRE(!(z1 && resid), "dwconv_bwd_data: resid only in the plain (z1 == NULL) form");
+  g.d_strip = make_fastdiv((Wi + 3) / 4); g.d_rows = make_fastdiv(Hi);
   const int nitems = B * Hi * ((Wi + 3) / 4);
   const int ipb = rows_per_block_for(nitems, nr_of(C));
   dim3 grid((nitems + ipb - 1) / ipb, cg_grid_y(C));
@@ -1099,7 +1117,7 @@ extern "C" int mmsim_stem_fwd(const float* x, const float* w, void* z, float* su
                               unsigned long long scratch_floats, void* stream) {
   MMSIM_REQUIRE(x && w && z && sums && B > 0 && Hi > 1 && Wi > 1, "stem_fwd: bad arguments"); REQ_C8(Co, "stem_fwd");
   MMSIM_REQUIRE(Co <= 64, "stem_fwd: at most 64 output channels");
-  StemGeom g; g.B = B; g.Hi = Hi; g.Wi = Wi; g.Ho = (Hi + 2 - 3) / 2 + 1; g.Wo = (Wi + 2 - 3) / 2 + 1; g.Co = Co;
+  StemGeom g; g.B = B; g.Hi = Hi; g.Wi = Wi; g.Ho = (Hi + 2 - 3) / 2 + 1; g.Wo = (Wi + 2 - 3) / 2 + 1; g.Co = Co; g.d_wo = make_fastdiv(g.Wo); g.d_ho = make_fastdiv(g.Ho);
   const int npix = B * g.Ho * g.Wo;
   const int ppb = rows_per_block_for(npix, nr_of(Co));
   const int nparts = (npix + ppb - 1) / ppb;
@@ -1112,7 +1130,7 @@ extern "C" int mmsim_stem_fwd(const float* x, const float* w, void* z, float* su
 extern "C" int mmsim_stem_wgrad(const void* dz, const float* x, float* dw, int B, int Hi, int Wi, int Co, void* stream) {
   MMSIM_REQUIRE(dz && x && dw && B > 0, "stem_wgrad: bad arguments"); REQ_C8(Co, "stem_wgrad");
   MMSIM_REQUIRE(Co <= 64, "stem_wgrad: at most 64 output channels");
-  StemGeom g; g.B = B; g.Hi = Hi; g.Wi = Wi; g.Ho = (Hi + 2 - 3) / 2 + 1; g.Wo = (Wi + 2 - 3) / 2 + 1; g.Co = Co;
+  StemGeom g; g.B = B; g.Hi = Hi; g.Wi = Wi; g.Ho = (Hi + 2 - 3) / 2 + 1; g.Wo = (Wi + 2 - 3) / 2 + 1; g.Co = Co; g.d_wo = make_fastdiv(g.Wo); g.d_ho = make_fastdiv(g.Ho);
   const int npix = B * g.Ho * g.Wo;
   const int ppb = 2048;
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3((npix + ppb - 1) / ppb), dim3(27 * (Co / 8) * SW_LANES), 0, (hipStream_t)stream, (const bf16*)dz, x, dw, g, ppb);

@@ -8,7 +8,7 @@ struct GemmParams {
   int c_f32, epi, atomic, accum, k_per_split, tiles_m, tiles_n, splits;
   float alpha;
   // optional operand transform (1x1 conv after BN + SiLU + squeeze-excite): x -> silu(scale[c] x + shift[c]) * gate[b, c]
-  const float* xf_scale; const float* xf_shift; const float* xf_gate; int xf_hw, xf_C;
+  const float* xf_scale; const float* xf_shift; const float* xf_gate; int xf_hw, xf_C; FastDiv xf_dhw;
   int dbg;   // ablation switches for tools/bench_gemm.py (MMSIM_GEMM_DBG): 1 no DMA, 2 no LDS reads, 4 no MFMA; 0 in production
 };
 
