@@ -171,19 +171,33 @@ __global__ __launch_bounds__(256) void pool_bn_act_kernel(const bf16* __restrict
     float sc[8], sh[8];
     ld8f(scale + m.cg * 8, sc); ld8f(shift + m.cg * 8, sh);
     const int rbeg = blockIdx.z * rows_per_z, rend = min(HW, rbeg + rows_per_z);
-#pragma unroll 2
-    for (int r = rbeg + m.rl; r < rend; r += m.nr) {
-      const size_t off = ((size_t)b * HW + r) * C + m.cg * 8;
-      float f[8];
-      unpack8(*reinterpret_cast<const uint4*>(z + off), f);
-      if (other) {
-        float o[8];
-        unpack8(*reinterpret_cast<const uint4*>(other + off), o);
+    // four rows per trip, all (bounds-masked) loads requested before the first use
+    const bf16* zb = z + (size_t)b * HW * C + m.cg * 8;
+    const bf16* ob = other ? other + (size_t)b * HW * C + m.cg * 8 : nullptr;
+    for (int r = rbeg + m.rl; r < rend; r += 4 * m.nr) {
+      uint4 zr[4], orr[4];
+      bool ok[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { float y = f[e] * sc[e] + sh[e]; if (act) y = silu_f(y); acc[e] += y * o[e]; }
-      } else {
+      for (int q = 0; q < 4; ++q) {
+        const int rq = r + q * m.nr;
+        ok[q] = rq < rend;
+        const size_t off = (size_t)min(rq, rend - 1) * C;
+        zr[q] = ld16_masked(zb + off, ok[q]);
+        if (ob) orr[q] = ld16_masked(ob + off, ok[q]);
+      }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { float y = f[e] * sc[e] + sh[e]; if (act) y = silu_f(y); acc[e] += y; }
+      for (int q = 0; q < 4; ++q) {
+        float f[8];
+        unpack8(zr[q], f);
+        if (ob) {
+          float o[8];
+          unpack8(orr[q], o);            // zero for rows past the end: they add nothing
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { float y = f[e] * sc[e] + sh[e]; if (act) y = silu_f(y); acc[e] += y * o[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { float y = f[e] * sc[e] + sh[e]; if (act) y = silu_f(y); acc[e] += ok[q] ? y : 0.f; }
+        }
       }
     }
   }
@@ -288,22 +302,43 @@ __global__ __launch_bounds__(64) void se_wgrad_kernel(const float* __restrict__ 
   const int r0 = blockIdx.y * 16;
   const int bq = (B + 3) / 4, b0 = blockIdx.z * bq, b1 = min(B, b0 + bq);
   const bool cok = c < C;
-  float ae[16], ar[16], ab = 0.f;
+  const int cc = min(c, C - 1);
+  __shared__ float hsl[64][16], drl[64][16];      // this block's 16 hidden units of hs / dr for 64 batch rows (zero padded)
+  float ae[16], ar[16], ab = 0.f, abr = 0.f;
 #pragma unroll
   for (int k = 0; k < 16; ++k) { ae[k] = 0.f; ar[k] = 0.f; }
-  for (int b = b0; b < b1; ++b) {
-    float d = 0.f, sv = 0.f;
-    if (cok) {
-      const float g = gate[(size_t)b * C + c];
-      d = dgate[(size_t)b * C + c] * g * (1.f - g);
-      sv = s[(size_t)b * C + c];
+  for (int bc = b0; bc < b1; bc += 64) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 16; i += 64) {
+      const int bb = i >> 4, k = i & 15;
+      const bool ok = bc + bb < b1 && r0 + k < R;
+      const size_t idx = (size_t)min(bc + bb, b1 - 1) * R + min(r0 + k, R - 1);
+      const float m = ok ? 1.f : 0.f;
+      hsl[bb][k] = hs[idx] * m;
+      drl[bb][k] = dr[idx] * m;
     }
-    ab += d;
-    const float* hrow = hs + (size_t)b * R + r0;
-    const float* drow = dr + (size_t)b * R + r0;
+    __syncthreads();
+    const int nb = min(64, b1 - bc);
+    for (int bb = 0; bb < nb; bb += 4) {          // four batch rows per trip: 12 loads in flight
+      float d[4], sv[4];
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if (r0 + k < R) { ae[k] += d * hrow[k]; ar[k] += drow[k] * sv; }
+      for (int q = 0; q < 4; ++q) {
+        const size_t off = (size_t)min(bc + bb + q, b1 - 1) * C + cc;
+        const float m = (cok && bb + q < nb) ? 1.f : 0.f;
+        const float g = gate[off];
+        d[q] = dgate[off] * g * (1.f - g) * m;
+        sv[q] = s[off] * m;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int bi = min(bb + q, 63);
+        ab += d[q];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { ae[k] += d[q] * hsl[bi][k]; ar[k] += drl[bi][k] * sv[q]; }
+      }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 16)
+      for (int bb = 0; bb < nb; ++bb) abr += drl[bb][threadIdx.x];
   }
   if (cok) {
 #pragma unroll
@@ -311,11 +346,7 @@ __global__ __launch_bounds__(64) void se_wgrad_kernel(const float* __restrict__ 
       if (r0 + k < R) { atomicAdd(dWeT + (size_t)(r0 + k) * C + c, ae[k]); atomicAdd(dWr + (size_t)(r0 + k) * C + c, ar[k]); }
     if (blockIdx.y == 0) atomicAdd(dbe + c, ab);
   }
-  if (blockIdx.x == 0 && threadIdx.x < 16 && r0 + threadIdx.x < R) {
-    float a = 0.f;
-    for (int b = b0; b < b1; ++b) a += dr[(size_t)b * R + r0 + threadIdx.x];
-    atomicAdd(dbr + r0 + threadIdx.x, a);
-  }
+  if (blockIdx.x == 0 && threadIdx.x < 16 && r0 + threadIdx.x < R) atomicAdd(dbr + r0 + threadIdx.x, abr);
 }
 
 // ------------------------------------------------------------------ BN (+SiLU, +SE gate) backward
