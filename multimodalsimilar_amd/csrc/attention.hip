@@ -68,12 +68,20 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_kernel(AttnParams p) {
   const bf16* base = p.qkv + (size_t)b * S * p.ld_qkv + h * 64;
 
   // stage K and V rows (8 x 16-byte chunks per row)
-  for (int c = tid; c < S * 8; c += 64 * NT) {
-    const int row = c >> 3, ch = c & 7;
-    const uint4 kv = *reinterpret_cast<const uint4*>(base + (size_t)row * p.ld_qkv + p.H + ch * 8);
-    const uint4 vv = *reinterpret_cast<const uint4*>(base + (size_t)row * p.ld_qkv + 2 * p.H + ch * 8);
-    *reinterpret_cast<uint4*>(Ks + row * ROW_PITCH + ch * 16) = kv;
-    *reinterpret_cast<uint4*>(Vs + row * TRV_PITCH + ch * 16) = vv;
+  {   // S*8 chunks over 64*NT threads = 4 trips: all 8 loads requested before the first LDS store
+    uint4 kv[4], vv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 64 * NT, row = c >> 3, ch = c & 7;
+      kv[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * p.ld_qkv + p.H + ch * 8);
+      vv[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * p.ld_qkv + 2 * p.H + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 64 * NT, row = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(Ks + row * ROW_PITCH + ch * 16) = kv[i];
+      *reinterpret_cast<uint4*>(Vs + row * TRV_PITCH + ch * 16) = vv[i];
+    }
   }
   for (int i = tid; i < S; i += 64 * NT) mb[i] = (p.mask && p.mask[(size_t)b * S + i] == 0) ? -1e30f : 0.f;
 
@@ -120,14 +128,17 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_kernel(AttnParams p) {
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
   if (hh == 0 && p.lse) p.lse[(size_t)bh * S + qrow] = mx + __logf(sum);
-  if (p.thresh) {
+  if (p.thresh) {                       // accumulator registers r, r+1 (r even) are keys k, k+1: one hash per pair
+    const uint32_t dkey = drop_key(p.seed, p.stream);
+    const unsigned long long rowbase = ((unsigned long long)bh * S + qrow) * S;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 16; r += 2) {
         const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const unsigned long long idx = ((unsigned long long)bh * S + qrow) * S + key;
-        sacc[kt][r] = drop_keep(p.seed, p.stream, idx, p.thresh) ? sacc[kt][r] * p.inv_keep : 0.f;
+        const uint32_t bits = drop_bits(dkey, (rowbase + key) >> 1);
+        sacc[kt][r] = drop_keep16(bits, 0, p.thresh) ? sacc[kt][r] * p.inv_keep : 0.f;
+        sacc[kt][r + 1] = drop_keep16(bits, 1, p.thresh) ? sacc[kt][r + 1] * p.inv_keep : 0.f;
       }
   }
   // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
@@ -172,14 +183,22 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
   const bf16* dob = p.dctx + (size_t)b * S * p.ld_ctx + h * 64;
   const bf16* ob = p.ctx + (size_t)b * S * p.ld_ctx + h * 64;
 
-  for (int c = tid; c < S * 8; c += 64 * NT) {
-    const int row = c >> 3, ch = c & 7;
-    *reinterpret_cast<uint4*>(Qs + row * ROW_PITCH + ch * 16) =
-        *reinterpret_cast<const uint4*>(base + (size_t)row * p.ld_qkv + ch * 8);
-    *reinterpret_cast<uint4*>(Ks + row * ROW_PITCH + ch * 16) =
-        *reinterpret_cast<const uint4*>(base + (size_t)row * p.ld_qkv + p.H + ch * 8);
-    *reinterpret_cast<uint4*>(Os + row * ROW_PITCH + ch * 16) =
-        *reinterpret_cast<const uint4*>(dob + (size_t)row * p.ld_ctx + ch * 8);
+  {   // 4 trips x 3 operands: all 12 loads requested before the first LDS store
+    uint4 qv[4], kv[4], ov[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 64 * NT, row = c >> 3, ch = c & 7;
+      qv[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * p.ld_qkv + ch * 8);
+      kv[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * p.ld_qkv + p.H + ch * 8);
+      ov[i] = *reinterpret_cast<const uint4*>(dob + (size_t)row * p.ld_ctx + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 64 * NT, row = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(Qs + row * ROW_PITCH + ch * 16) = qv[i];
+      *reinterpret_cast<uint4*>(Ks + row * ROW_PITCH + ch * 16) = kv[i];
+      *reinterpret_cast<uint4*>(Os + row * ROW_PITCH + ch * 16) = ov[i];
+    }
   }
   for (int i = tid; i < S; i += 64 * NT) {
     mb[i] = (p.mask && p.mask[(size_t)b * S + i] == 0) ? -1e30f : 0.f;
@@ -208,6 +227,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
   }
   __syncthreads();
   const float mbk = mb[key];
+  const uint32_t dkey = drop_key(p.seed, p.stream);
 
   f16v dV[2], dK[2];
 #pragma unroll
@@ -235,7 +255,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
       float ks = 1.0f;
       if (p.thresh) {
         const unsigned long long idx = ((unsigned long long)bh * S + q) * S + key;
-        ks = drop_keep(p.seed, p.stream, idx, p.thresh) ? p.inv_keep : 0.f;
+        ks = drop_keep16(drop_bits(dkey, idx >> 1), key & 1, p.thresh) ? p.inv_keep : 0.f;
       }
       X[r] = pr * ks;
       dP[r] = pr * (dP[r] * ks - dl[q]);

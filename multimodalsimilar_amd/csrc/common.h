@@ -75,18 +75,23 @@ __device__ __forceinline__ float silu_grad_f(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
-// Counter-based dropout RNG: one 32-bit hash per element, keyed by (seed, stream, index).
-// keep iff hash >= threshold; threshold = p * 2^32.  Deterministic, recomputed in backward.
+// Counter-based dropout RNG, deterministic and recomputed in backward.  One 32-bit hash serves TWO consecutive
+// elements (16 bits each): keep element idx iff bits16(hash(idx >> 1), idx & 1) >= p * 2^16.  The (seed, stream) part
+// of the key is loop-invariant, so an element costs about four integer instructions (it used to be two full hashes per
+// element, which made the attention kernels VALU-bound on the mask alone).
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint32_t stream, uint64_t idx) {
-  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-  uint32_t h = hash32(lo ^ (uint32_t)seed);
-  h = hash32(h + hi * 0x9E3779B9U + stream * 0x85EBCA6BU + (uint32_t)(seed >> 32));
-  return h;
+__device__ __forceinline__ uint32_t drop_key(uint64_t seed, uint32_t stream) {
+  return hash32((uint32_t)seed ^ hash32(stream * 0x85EBCA6BU + (uint32_t)(seed >> 32) * 0x9E3779B9U + 0x632BE5ABU));
+}
+__device__ __forceinline__ uint32_t drop_bits(uint32_t key, uint64_t pair_idx) {     // 2 x 16 random bits for elements 2*pair_idx, +1
+  return hash32((uint32_t)pair_idx ^ key ^ ((uint32_t)(pair_idx >> 32) * 0x9E3779B9U));
+}
+__device__ __forceinline__ bool drop_keep16(uint32_t bits, int odd, uint32_t thresh) {
+  return ((odd ? bits >> 16 : bits & 0xffffU) >= (thresh >> 16));
 }
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t stream, uint64_t idx, uint32_t thresh) {
-  return rng_u32(seed, stream, idx) >= thresh;
+  return drop_keep16(drop_bits(drop_key(seed, stream), idx >> 1), (int)(idx & 1), thresh);
 }

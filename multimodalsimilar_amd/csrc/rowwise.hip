@@ -27,12 +27,14 @@ static Drop make_drop(float p, unsigned long long seed, unsigned int stream) {
   d.inv_keep = 1.0f / (1.0f - p);
   return d;
 }
-__device__ __forceinline__ float4 drop4(float4 v, const Drop& d, unsigned long long idx) {
+__device__ __forceinline__ float4 drop4(float4 v, const Drop& d, unsigned long long idx) {     // idx: a multiple of 4
   if (!d.thresh) return v;
-  v.x = drop_keep(d.seed, d.stream, idx, d.thresh) ? v.x * d.inv_keep : 0.f;
-  v.y = drop_keep(d.seed, d.stream, idx + 1, d.thresh) ? v.y * d.inv_keep : 0.f;
-  v.z = drop_keep(d.seed, d.stream, idx + 2, d.thresh) ? v.z * d.inv_keep : 0.f;
-  v.w = drop_keep(d.seed, d.stream, idx + 3, d.thresh) ? v.w * d.inv_keep : 0.f;
+  const uint32_t key = drop_key(d.seed, d.stream);
+  const uint32_t h0 = drop_bits(key, idx >> 1), h1 = drop_bits(key, (idx >> 1) + 1);
+  v.x = drop_keep16(h0, 0, d.thresh) ? v.x * d.inv_keep : 0.f;
+  v.y = drop_keep16(h0, 1, d.thresh) ? v.y * d.inv_keep : 0.f;
+  v.z = drop_keep16(h1, 0, d.thresh) ? v.z * d.inv_keep : 0.f;
+  v.w = drop_keep16(h1, 1, d.thresh) ? v.w * d.inv_keep : 0.f;
   return v;
 }
 
