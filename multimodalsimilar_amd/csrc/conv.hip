@@ -964,7 +964,7 @@ extern "C" int mmsim_bn_stats(const void* z, float* sums, int P, int C, float* s
   const int nparts = (P + rpb - 1) / rpb;
   REQ_SCRATCH((size_t)nparts * 2 * C, "bn_stats");
   hipLaunchKernelGGL(bn_stats_kernel, dim3(nparts, cg_grid_y(C)), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scratch, P, C, rpb);
-  launch_reduce(scratch, nparts, 2 * C, sums, 0, (hipStream_t)stream);
+  launch_reduce(scratch, nparts, 2 * C, sums, 1, (hipStream_t)stream);      /* sums are pre-zeroed by the caller (header contract) */
   return mmsim_check_launch("bn_stats");
 }
 
@@ -1057,7 +1057,7 @@ extern "C" int mmsim_bn_bwd(const void* dy, const void* z, const float* mean, co
   if (!sums_ready) {
     REQ_SCRATCH((size_t)grid.x * 2 * C, "bn_bwd");
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, scratch, rpb);
-    launch_reduce(scratch, grid.x, 2 * C, sums, 0, (hipStream_t)stream);
+    launch_reduce(scratch, grid.x, 2 * C, sums, 1, (hipStream_t)stream);
   }
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, sums, (bf16*)dz, dgamma, dbeta, rpb);
   return mmsim_check_launch("bn_bwd");
@@ -1108,7 +1108,7 @@ extern "C" int mmsim_dwconv_fwd(const void* a, const float* w_tap_major, void* z
   if (Vv == 1) { DWF_KS(4, 1) } else if (Vv == 2) { DWF_KS(4, 2) } else { DWF_KS(4, 0) }
 #undef DWF_KS
 #undef DWF
-  launch_reduce(scratch, grid.x, 2 * C, sums, 0, (hipStream_t)stream);
+  launch_reduce(scratch, grid.x, 2 * C, sums, 1, (hipStream_t)stream);
   return mmsim_check_launch("dwconv_fwd");
 }
 
@@ -1127,7 +1127,7 @@ extern "C" int mmsim_dwconv_bwd_data(const void* dz, const float* w_tap_major, c
   if (z1) REQ_SCRATCH((size_t)grid.x * 2 * C, "dwconv_bwd_data");
   DW_DISPATCH(dwconv_bwd_data_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, w_tap_major, (const bf16*)z1, mean,
               rstd, scale, shift, (const bf16*)resid, (bf16*)dpre, scratch, g, ipb)
-  if (z1) launch_reduce(scratch, grid.x, 2 * C, sums, 0, (hipStream_t)stream);
+  if (z1) launch_reduce(scratch, grid.x, 2 * C, sums, 1, (hipStream_t)stream);
   return mmsim_check_launch("dwconv_bwd_data");
 }
 
@@ -1154,7 +1154,7 @@ extern "C" int mmsim_stem_fwd(const float* x, const float* w, void* z, float* su
   const int nparts = (npix + ppb - 1) / ppb;
   REQ_SCRATCH((size_t)nparts * 2 * Co, "stem_fwd");
   hipLaunchKernelGGL(stem_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)z, scratch, g, ppb);
-  launch_reduce(scratch, nparts, 2 * Co, sums, 0, (hipStream_t)stream);
+  launch_reduce(scratch, nparts, 2 * Co, sums, 1, (hipStream_t)stream);
   return mmsim_check_launch("stem_fwd");
 }
 

@@ -362,6 +362,15 @@ class EfficientNet(nn.Module):
         return st
 
     # ------------------------------------------------------------------ backward
+    def _zero_gT(self, st):
+        """Tap-major depthwise weight gradients of all blocks: one zeroed buffer per step instead of a fill per block."""
+        st.gT_off, tot = {}, 0
+        for blk in self.arch.blocks:
+            st.gT_off[blk.name] = tot
+            tot += blk.k * blk.k * blk.mid
+        st.gT_all = self._buf("gT_all", (tot,), torch.float32)
+        st.gT_all.zero_()
+
     def _bn_bwd(self, st, name, dy, z, P, C, dz, act, gate=None, dsq=None, hw=1, sums_ready=False):
         fl = self._flat
         sums = self._sums(st, name, "b")
@@ -404,7 +413,9 @@ class EfficientNet(nn.Module):
         dz2 = E(P_out, b.mid)
         self._bn_bwd(st, n + "." + d_bn, da2g, bs.z2, P_out, b.mid, dz2, act=True, gate=bs.gate, dsq=ds, hw=Ho * Wo)
         del da2g
-        gT = torch.zeros(b.k * b.k, b.mid, dtype=torch.float32, device=dev)
+        if not hasattr(st, "gT_all"):
+            self._zero_gT(st)
+        gT = st.gT_all[st.gT_off[n]:st.gT_off[n] + b.k * b.k * b.mid]
         lib.dwconv_bwd_weight(dz2.data_ptr(), bs.a1.data_ptr(), gT.data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride, *self._scr(), s)
         lib.dw_grad_from_tap_major(gT.data_ptr(), G(n + ".conv_dw.weight").data_ptr(), b.mid, b.k, s)
         if b.type == "ir":
@@ -443,6 +454,7 @@ class EfficientNet(nn.Module):
         V, G, SV = fl.view, fl.gview, fl.sview
         st.sums_b = self._buf("sums_b", (2 * self._bn_total,), torch.float32)
         st.sums_b.zero_()
+        self._zero_gT(st)
         dpooled = dpooled.contiguous().float()
         # ---- head
         H, W = st.Hh, st.Wh
