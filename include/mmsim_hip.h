@@ -48,6 +48,14 @@ int mmsim_gemm_bf16_xf(int xf_operand, int M, int N, int K, const void* A, int l
                        int ldc, int c_is_f32, const float* xf_scale, const float* xf_shift, const float* xf_gate,
                        int xf_hw, int split_k, int accumulate, void* stream);
 
+/* Forward 1x1 conv (xf_operand 0: plain, 1: BN + SiLU (+ gate) applied to A while staged) that also ACCUMULATES the
+ * train-mode BatchNorm statistics of its bf16 output into sums [2][N] (sum, sum of squares; pre-zeroed by the caller):
+ * replaces conv + the statistics pass of the following nn.BatchNorm2d (timm conv_pw / conv_pwl / conv_head + bn).
+ * scratch: >= ceil(M/128) * 2 * N floats. */
+int mmsim_gemm_bf16_bnstats(int xf_operand, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                            int ldc, const float* xf_scale, const float* xf_shift, const float* xf_gate, int xf_hw,
+                            float* sums, float* scratch, unsigned long long scratch_floats, void* stream);
+
 /* ---- self-attention (modeling_bert.py:111-136, 164-203), head_dim 64, S in {32, 64, 128} ----------
  * qkv: bf16 [B*S, ld_qkv] with q | k | v column blocks of width H; mask: int64 [B,S] (1 keep / 0 pad)
  * or NULL; ctx: bf16 [B*S, ld_ctx]; lse: fp32 [B*heads*S] log-sum-exp saved for backward. */

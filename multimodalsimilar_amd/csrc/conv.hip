@@ -93,7 +93,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   __syncthreads();
   if (wv == 0 && i < n) atomicAdd(out + i, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
+void mmsim_launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s);
 static void launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s) {
+  mmsim_launch_reduce(parts, nparts, n, out, accumulate, s);
+}
+void mmsim_launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s) {
   if (!accumulate) (void)hipMemsetAsync(out, 0, (size_t)n * sizeof(float), s);
   int gy = nparts / 16; if (gy > 8) gy = 8; if (gy < 1) gy = 1;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 63) / 64, gy), dim3(256), 0, s, parts, nparts, n, out);

@@ -192,6 +192,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     const bool fs = split == 0;
     const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;
     float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
+    if (p.stats) {                     // launch-uniform: bf16 output + BatchNorm column statistics of this M-tile
+      float cs[4], cq[4];
+      stats_epilogue(p, acc, row0, col0, lane, stg, cs, cq);
+      __syncthreads();                 // all staging reads done: the region is reused for the cross-wave sum
+      float* red = reinterpret_cast<float*>(smem);          // [wave][2][64]
+      if (lane < 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[(wave * 2 + 0) * 64 + lane * 4 + e] = cs[e]; red[(wave * 2 + 1) * 64 + lane * 4 + e] = cq[e]; }
+      }
+      __syncthreads();
+      if (wm == 0) {                   // waves 0, 1 (wn = 0, 1) add their partner wave (wm = 1) and write 64 columns each
+        const int n = col0 + lane;
+        if (n < p.N) {
+          float* slab = p.stats + (size_t)tm * 2 * p.N;
+          slab[n] = red[(wave * 2 + 0) * 64 + lane] + red[((wave + 2) * 2 + 0) * 64 + lane];
+          slab[p.N + n] = red[(wave * 2 + 1) * 64 + lane] + red[((wave + 2) * 2 + 1) * 64 + lane];
+        }
+      }
+      return;
+    }
     if (!p.c_f32) fast_epilogue_epi<0, true>(p, acc, row0, col0, lane, fs, stg);
     else if (p.atomic) fast_epilogue<EPI_NONE, 3, true>(p, acc, row0, col0, lane, fs, stg);
     else if (p.accum) fast_epilogue<EPI_NONE, 2, true>(p, acc, row0, col0, lane, fs, stg);
@@ -215,7 +235,7 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
                      int ldb, void* C, int ldc, int c_is_f32, const float* bias, int epilogue,
                      const void* aux_in, void* aux_out, int ld_aux, float alpha, int split_k,
                      int accumulate, int xf_operand, const float* xf_scale, const float* xf_shift, const float* xf_gate,
-                     int xf_hw, void* stream) {
+                     int xf_hw, void* stream, float* stats = nullptr) {
   MMSIM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: M, N, K must be positive");
   MMSIM_REQUIRE(A && B && C, "gemm: null operand");
   MMSIM_REQUIRE((lda % 8) == 0 && (ldb % 8) == 0, "gemm: lda/ldb must be multiples of 8 elements (16-byte rows)");
@@ -239,6 +259,7 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   p.c_f32 = c_is_f32; p.epi = epilogue; p.atomic = split_k > 1; p.accum = accumulate; p.alpha = alpha;
   p.xf_scale = xf_scale; p.xf_shift = xf_shift; p.xf_gate = xf_gate; p.xf_hw = xf_hw > 0 ? xf_hw : 1; p.xf_dhw = make_fastdiv(p.xf_hw);
   p.xf_C = (xf_operand == 1) ? K : N;
+  p.stats = stats;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MMSIM_GEMM_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
   int kps = (K + split_k - 1) / split_k;
@@ -249,7 +270,7 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   dim3 grid(p.tiles_m * p.tiles_n * splits), block(256);
   const size_t lds = 2 * STAGE_BYTES;
   hipStream_t s = (hipStream_t)stream;
-  if (xf_operand == 0 && !force_generic() && gemm_fast_eligible(p, splits)) {
+  if (xf_operand == 0 && !stats && !force_generic() && gemm_fast_eligible(p, splits)) {
     gemm_fast_launch(p, trans_a, b_kmajor, splits, s);
     return mmsim_check_launch("gemm_bf16_fast");
   }
@@ -298,4 +319,23 @@ extern "C" int mmsim_gemm_bf16_xf(int xf_operand, int M, int N, int K, const voi
   MMSIM_REQUIRE(((xf_operand == 1 ? K : N) % 8) == 0, "gemm_xf: transformed channel count must be a multiple of 8");
   return gemm_impl(xf_operand == 2, xf_operand == 1, M, N, K, A, lda, B, ldb, C, ldc, c_is_f32, nullptr, 0, nullptr, nullptr, 0,
                    1.0f, split_k, accumulate, xf_operand, xf_scale, xf_shift, xf_gate, xf_hw, stream);
+}
+
+void mmsim_launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s);   // conv.hip
+
+// 1x1 conv (optionally with the BN + SiLU (+ gate) operand transform, xf_operand = 1) whose epilogue also accumulates the
+// per-channel sum / sum of squares of the bf16-rounded output: the train-mode BatchNorm statistics of the conv output.
+extern "C" int mmsim_gemm_bf16_bnstats(int xf_operand, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                                       void* C, int ldc, const float* xf_scale, const float* xf_shift, const float* xf_gate,
+                                       int xf_hw, float* sums, float* scratch, unsigned long long scratch_floats, void* stream) {
+  MMSIM_REQUIRE(xf_operand == 0 || xf_operand == 1, "gemm_bnstats: xf_operand must be 0 (plain) or 1 (transform A)");
+  MMSIM_REQUIRE(xf_operand == 0 || (xf_scale && xf_shift), "gemm_bnstats: scale/shift required with xf_operand 1");
+  MMSIM_REQUIRE(sums && (N % 8) == 0, "gemm_bnstats: sums required, N must be a multiple of 8");
+  const int tiles_m = (M + BM - 1) / BM;
+  MMSIM_REQUIRE(scratch && (unsigned long long)tiles_m * 2 * N <= scratch_floats, "gemm_bnstats: scratch too small (need ceil(M/128)*2*N floats)");
+  const int rc = gemm_impl(0, 1, M, N, K, A, lda, B, ldb, C, ldc, 0, nullptr, 0, nullptr, nullptr, 0, 1.0f, 1, 0, xf_operand,
+                           xf_scale, xf_shift, xf_gate, xf_hw, stream, scratch);
+  if (rc) return rc;
+  mmsim_launch_reduce(scratch, tiles_m, 2 * N, sums, 1, (hipStream_t)stream);
+  return mmsim_check_launch("gemm_bnstats");
 }

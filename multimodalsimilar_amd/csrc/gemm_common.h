@@ -9,6 +9,7 @@ struct GemmParams {
   float alpha;
   // optional operand transform (1x1 conv after BN + SiLU + squeeze-excite): x -> silu(scale[c] x + shift[c]) * gate[b, c]
   const float* xf_scale; const float* xf_shift; const float* xf_gate; int xf_hw, xf_C; FastDiv xf_dhw;
+  float* stats;   // gemm_bf16_kernel, bf16 output, no split: per-M-tile column sum / sumsq slab [tiles_m][2][N] (NULL = off)
   int dbg;   // ablation switches for tools/bench_gemm.py (MMSIM_GEMM_DBG): 1 no DMA, 2 no LDS reads, 4 no MFMA; 0 in production
 };
 
@@ -101,6 +102,38 @@ __device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][
   }
 }
 
+
+// bf16 store of a 64x64 sub-tile (no bias / activation: the 1x1 convs) that also returns the column sums of the ROUNDED
+// outputs -- the train-mode BatchNorm statistics of the conv output, so no separate pass re-reads it.
+// cs / cq: lanes 0..15 end up with sum / sum of squares of columns col0 + 4*(lane&15) + {0..3} over this wave's valid rows.
+__device__ __forceinline__ void stats_epilogue(const GemmParams& p, f4 (&acc)[4][4], int row0, int col0, int lane, float* tile,
+                                               float (&cs)[4], float (&cq)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f4*>(tile + (i * 16 + (lane & 15)) * EP_PITCH + j * 16 + (lane >> 4) * 4) = acc[i][j];
+  const int c4 = (lane & 15) * 4, n = col0 + c4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) cs[e] = cq[e] = 0.f;
+  if (n < p.N) {                       // N % 8 == 0 (checked on the host): a 4-column group is valid as a whole
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int r = it * 4 + (lane >> 4);
+      if (row0 + r >= p.M) continue;
+      const f4 a = *reinterpret_cast<const f4*>(tile + r * EP_PITCH + c4);
+      bf4 o = {f2bf(a[0] * p.alpha), f2bf(a[1] * p.alpha), f2bf(a[2] * p.alpha), f2bf(a[3] * p.alpha)};
+      *reinterpret_cast<bf4*>(reinterpret_cast<bf16*>(p.C) + (size_t)(row0 + r) * p.ldc + n) = o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float v = bf2f(o[e]); cs[e] += v; cq[e] += v * v; }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    cs[e] += __shfl_xor(cs[e], 16, 64); cs[e] += __shfl_xor(cs[e], 32, 64);
+    cq[e] += __shfl_xor(cq[e], 16, 64); cq[e] += __shfl_xor(cq[e], 32, 64);
+  }
+}
 
 template <int CMODE, bool CHECK = false>
 __device__ __forceinline__ void fast_epilogue_epi(const GemmParams& p, f4 (&acc)[4][4], int row0, int col0, int lane, bool first_split,

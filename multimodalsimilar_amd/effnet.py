@@ -274,9 +274,10 @@ class EfficientNet(nn.Module):
         P_in = B * H * W
         if b.type == "ir":
             bs.z1 = E(P_in, b.mid)
-            ops.gemm(cur, SV(n + ".conv_pw.weight", (b.mid, b.cin)), bs.z1)
             sm = self._sums(st, n + "." + e_bn, "f")
-            lib.bn_stats(bs.z1.data_ptr(), sm.data_ptr(), P_in, b.mid, *self._scr(), s)
+            w1 = SV(n + ".conv_pw.weight", (b.mid, b.cin))
+            lib.gemm_bf16_bnstats(0, P_in, b.mid, b.cin, cur.data_ptr(), b.cin, w1.data_ptr(), b.cin, bs.z1.data_ptr(), b.mid,
+                                  None, None, None, 1, sm.data_ptr(), *self._scr(), s)     # conv + the BN statistics of z1
             self._bn_finalize(st, n + "." + e_bn, sm, P_in)
             bs.a1 = E(P_in, b.mid)
             lib.bn_apply(bs.z1.data_ptr(), self._bnp(st, n + "." + e_bn, 2).data_ptr(),
@@ -305,10 +306,9 @@ class EfficientNet(nn.Module):
         pw = n + (".conv_pw" if b.type == "ds" else ".conv_pwl")
         bs.z3 = E(P_out, b.cout)
         w3 = SV(pw + ".weight", (b.cout, b.mid))
-        lib.gemm_bf16_xf(1, P_out, b.cout, b.mid, bs.z2.data_ptr(), b.mid, w3.data_ptr(), b.mid, bs.z3.data_ptr(), b.cout, 0,
-                         sc2.data_ptr(), sh2.data_ptr(), bs.gate.data_ptr(), Ho * Wo, 1, 0, s)
         sm = self._sums(st, n + "." + p_bn, "f")
-        lib.bn_stats(bs.z3.data_ptr(), sm.data_ptr(), P_out, b.cout, *self._scr(), s)
+        lib.gemm_bf16_bnstats(1, P_out, b.cout, b.mid, bs.z2.data_ptr(), b.mid, w3.data_ptr(), b.mid, bs.z3.data_ptr(), b.cout,
+                              sc2.data_ptr(), sh2.data_ptr(), bs.gate.data_ptr(), Ho * Wo, sm.data_ptr(), *self._scr(), s)
         self._bn_finalize(st, n + "." + p_bn, sm, P_out)
         nxt = E(P_out, b.cout)
         lib.bn_apply(bs.z3.data_ptr(), self._bnp(st, n + "." + p_bn, 2).data_ptr(), self._bnp(st, n + "." + p_bn, 3).data_ptr(),
@@ -350,9 +350,10 @@ class EfficientNet(nn.Module):
         P = B * H * W
         st.x_last, st.Hh, st.Wh = cur, H, W
         st.zh = E(P, a.head)
-        ops.gemm(cur, SV("conv_head.weight", (a.head, a.last)), st.zh)
         sm = self._sums(st, "bn2", "f")
-        lib.bn_stats(st.zh.data_ptr(), sm.data_ptr(), P, a.head, *self._scr(), s)
+        wh = SV("conv_head.weight", (a.head, a.last))
+        lib.gemm_bf16_bnstats(0, P, a.head, a.last, cur.data_ptr(), a.last, wh.data_ptr(), a.last, st.zh.data_ptr(), a.head,
+                              None, None, None, 1, sm.data_ptr(), *self._scr(), s)
         self._bn_finalize(st, "bn2", sm, P)
         st.pooled = E(B, a.head, dt=torch.float32)
         lib.pool_bn_act(st.zh.data_ptr(), self._bnp(st, "bn2", 2).data_ptr(), self._bnp(st, "bn2", 3).data_ptr(), None,

@@ -324,3 +324,33 @@ def test_cv_classifier_matches_oracle(name, use_fc):
     assert torch.allclose(rm, 0.1 * mu * 1.9, atol=2e-3)
     assert torch.allclose(rv, 0.81 + 0.19 * var * n / (n - 1), rtol=2e-2, atol=2e-3)
     assert int(model.backbone.bn1.num_batches_tracked) == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,Cin,Cout,xf", [(1000, 24, 144, 0), (6272, 96, 40, 1), (513, 48, 24, 0), (12544, 272, 448, 1)])
+def test_pointwise_conv_with_bn_statistics(P, Cin, Cout, xf):
+    """conv_pw / conv_pwl + the statistics pass of the following BatchNorm2d in one launch: output equals the plain GEMM,
+    sums equal sum / sum of squares of the bf16-rounded output (ragged M, N tiles included)."""
+    torch.manual_seed(P + Cin)
+    hw = 49
+    B = (P + hw - 1) // hw
+    x = torch.randn(P, Cin, device=DEV).bfloat16()
+    w = (torch.randn(Cout, Cin, device=DEV) * 0.2).bfloat16()
+    sc, sh = torch.rand(Cin, device=DEV) + 0.5, torch.randn(Cin, device=DEV) * 0.3
+    gate = torch.rand(B, Cin, device=DEV)
+    z = torch.empty(P, Cout, dtype=torch.bfloat16, device=DEV)
+    sums = torch.zeros(2 * Cout, device=DEV)
+    lib, s = _lib()
+    lib.gemm_bf16_bnstats(xf, P, Cout, Cin, x.data_ptr(), Cin, w.data_ptr(), Cin, z.data_ptr(), Cout,
+                          sc.data_ptr() if xf else None, sh.data_ptr() if xf else None, gate.data_ptr() if xf else None, hw,
+                          sums.data_ptr(), *scr(), s)
+    a = x.float()
+    if xf:
+        a = torch.nn.functional.silu(a * sc + sh) * gate.repeat_interleave(hw, 0)[:P]
+        a = a.bfloat16().float()
+    ref = a @ w.float().t()
+    assert relerr(z, ref) < 1e-2
+    zf = z.float()
+    ssum, ssq = zf.double().sum(0), (zf.double() ** 2).sum(0)
+    assert (sums[:Cout].double() - ssum).abs().max() < 1e-4 * zf.abs().double().sum(0).max() + 1e-3      # fp32 summation order
+    assert (sums[Cout:].double() - ssq).abs().max() < 1e-4 * ssq.max() + 1e-3
