@@ -137,6 +137,16 @@ int mmsim_bn_apply(const void* z, const float* scale, const float* shift, const 
 /* out[b,c] = mul * sum_hw act(scale*z+shift) * (other ? other : 1): SE squeeze / global pool (mul = 1/HW), SE dgate. */
 int mmsim_pool_bn_act(const void* z, const float* scale, const float* shift, const void* other, float* out, int B,
                       int HW, int C, int act_silu, float mul, void* stream);
+
+/* Backward of the SE squeeze and, in the same pass over (z, dy), the partial sums from which the depthwise BatchNorm's
+ * backward batch sums follow once the SE backward has produced dsq (timm SqueezeExcite + bn2 + act under cv_classifier.py:49):
+ * out5 [5][B][C] fp32: [0] dgate = sum_hw silu(bn z) dy; [1..4] = sum_hw dy a', a', dy a' zhat, a' zhat  (a' = silu'(bn z)).
+ * mmsim_bn_bwd_sums_from_pool then accumulates into sums [2][C] (pre-zeroed) the batch sums of da and da*zhat, da = (dy gate + dsq/HW) a', which
+ * mmsim_bn_bwd consumes with sums_ready = 1. */
+int mmsim_pool_bn_bwd(const void* z, const float* scale, const float* shift, const float* mean, const float* rstd,
+                      const void* dy, float* out5, int B, int HW, int C, void* stream);
+int mmsim_bn_bwd_sums_from_pool(const float* out5, const float* gate, const float* dsq, float* sums, int B, int HW, int C,
+                                void* stream);
 /* Squeeze-excite: hr = W_reduce s + b_reduce (saved pre-activation; hs = silu(hr) saved too); gate = sigmoid(W_expand silu(hr) + b_expand).
  * weT [RD][C] receives conv_expand.weight transposed (kept for the backward of the same step).  Backward: from
  * dgate [B,C] produces dr [B,RD], ds [B,C] (gradient of the squeezed input) and accumulates the four parameter

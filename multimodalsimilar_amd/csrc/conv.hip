@@ -31,6 +31,22 @@ __device__ __forceinline__ CgMap cg_map(int C) {
 }
 static inline int cg_grid_y(int C) { const int G = C >> 3; return G >= 256 ? (G + 255) / 256 : 1; }
 
+// Map for the per-image pooling kernels: at most 32 octets per block, so wide layers get >= 8 row lanes per block (their
+// planes are small: 14x14, 7x7) and the image's whole plane fits one block without a z-split and its atomics.
+__device__ __forceinline__ CgMap pool_map(int C) {
+  CgMap m;
+  const int G = C >> 3;
+  m.G = G >= 32 ? 32 : G;                       // octets per block (stride of the LDS reduction)
+  m.nr = 256 / m.G;
+  const int lc = threadIdx.x % m.G;
+  m.rl = threadIdx.x / m.G;
+  m.cg = blockIdx.y * m.G + lc;
+  m.active = m.rl < m.nr && m.cg < G;
+  return m;
+}
+static inline int pool_grid_y(int C) { const int G = C >> 3; return G >= 32 ? (G + 31) / 32 : 1; }
+static inline int pool_nr(int C) { const int G = C >> 3; return 256 / (G >= 32 ? 32 : G); }
+
 // Reduce acc[NV] over the row-lanes of a block (same channel octet) and STORE the block's partial result:
 // value i goes to base[(i/8)*stat_stride + c0 + i%8], base = this block's slot of a [nparts][...] scratch.
 // A second tiny kernel (reduce_partials) sums the slots: a thousand blocks atomically adding into the same few
@@ -166,7 +182,8 @@ __global__ __launch_bounds__(256) void pool_bn_act_kernel(const bf16* __restrict
                                                           const float* __restrict__ shift, const bf16* __restrict__ other,
                                                           float* out, int HW, int C, int act, float mul, int rows_per_z) {
   __shared__ float lds[256 * 8];
-  const CgMap m = cg_map(C);
+  const CgMap m = pool_map(C);
+  const int lc = threadIdx.x % m.G;
   const int b = blockIdx.x;
   float acc[8];
 #pragma unroll
@@ -212,7 +229,7 @@ __global__ __launch_bounds__(256) void pool_bn_act_kernel(const bf16* __restrict
   if (m.active && m.rl == 0) {
     for (int r = 1; r < m.nr; ++r)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += lds[(m.cg + r * m.G) * 8 + e];
+      for (int e = 0; e < 8; ++e) acc[e] += lds[(lc + r * m.G) * 8 + e];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       if (gridDim.z == 1) out[(size_t)b * C + m.cg * 8 + e] = acc[e] * mul;
@@ -354,6 +371,105 @@ __global__ __launch_bounds__(64) void se_wgrad_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------ BN (+SiLU, +SE gate) backward
+// Backward of the squeeze (SE) branch AND the batch sums of the depthwise BatchNorm backward in ONE pass over (z, dy):
+// with u = scale z + shift, a = silu(u), a' = silu'(u), zh = (z - mean) rstd and dy the gradient w.r.t. the gated activation,
+//   out5[0][b,c] = sum_hw a dy          (dgate, the SE backward input)
+//   out5[1..4]   = sum_hw dy a',  sum_hw a',  sum_hw dy a' zh,  sum_hw a' zh
+// The BN-backward sums of da = (dy gate + dsq / HW) a' are then  S1[c] = sum_b gate P1 + dsq/HW P2,  S2[c] = sum_b gate P3 +
+// dsq/HW P4 (bn_bwd_sums_from_pool_kernel) -- dsq only exists after the SE backward, which needs dgate, so without this
+// regrouping the reduction costs a second full pass over both tensors (bn_bwd_reduce_kernel).
+__global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const bf16* __restrict__ z, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const bf16* __restrict__ dy,
+                                                          float* out5, int B, int HW, int C, int rows_per_z) {
+  __shared__ float lds[256 * 8];
+  const CgMap m = pool_map(C);
+  const int lc = threadIdx.x % m.G;
+  const int b = blockIdx.x;
+  float acc[5][8];
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+  if (m.active) {
+    float sc[8], sh[8], mu[8], rs[8];
+    ld8f(scale + m.cg * 8, sc); ld8f(shift + m.cg * 8, sh); ld8f(mean + m.cg * 8, mu); ld8f(rstd + m.cg * 8, rs);
+    const int rbeg = blockIdx.z * rows_per_z, rend = min(HW, rbeg + rows_per_z);
+    const bf16* zb = z + (size_t)b * HW * C + m.cg * 8;
+    const bf16* db = dy + (size_t)b * HW * C + m.cg * 8;
+    for (int r = rbeg + m.rl; r < rend; r += 4 * m.nr) {
+      uint4 zr[4], dr[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rq = r + q * m.nr;
+        const size_t off = (size_t)min(rq, rend - 1) * C;
+        zr[q] = ld16_masked(zb + off, rq < rend);
+        dr[q] = ld16_masked(db + off, rq < rend);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float ok = (r + q * m.nr < rend) ? 1.f : 0.f;     // a' of a masked (zero) z is not zero
+        float f[8], d[8];
+        unpack8(zr[q], f); unpack8(dr[q], d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float u = f[e] * sc[e] + sh[e], sg = sigmoid_f(u);
+          const float a = u * sg, da = sg * (1.0f + u * (1.0f - sg)) * ok, zh = (f[e] - mu[e]) * rs[e];
+          acc[0][e] += a * d[e];
+          acc[1][e] += d[e] * da; acc[2][e] += da;
+          acc[3][e] += d[e] * da * zh; acc[4][e] += da * zh;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds[threadIdx.x * 8 + e] = acc[k][e];
+    __syncthreads();
+    if (m.active && m.rl == 0) {
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = acc[k][e];
+      for (int r = 1; r < m.nr; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] += lds[(lc + r * m.G) * 8 + e];
+      float* o = out5 + ((size_t)k * B + b) * C + m.cg * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (gridDim.z == 1) o[e] = t[e];
+        else atomicAdd(o + e, t[e]);
+      }
+    }
+  }
+}
+
+// sums[0][c] = sum_b gate P1 + dsq/HW P2,  sums[1][c] = sum_b gate P3 + dsq/HW P4;  block = 64 channels x 4 batch lanes
+__global__ __launch_bounds__(256) void bn_bwd_sums_from_pool_kernel(const float* __restrict__ out5, const float* __restrict__ gate,
+                                                                    const float* __restrict__ dsq, float* sums, int B, int C, float inv_hw) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, bl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    const size_t BC = (size_t)B * C;
+    const int bq = (B + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * bq, b1 = min(B, b0 + bq);
+    for (int b = b0 + bl; b < b1; b += 4) {
+      const size_t i = (size_t)b * C + c;
+      const float g = gate[i], q = dsq[i] * inv_hw;
+      s1 += g * out5[BC + i] + q * out5[2 * BC + i];
+      s2 += g * out5[3 * BC + i] + q * out5[4 * BC + i];
+    }
+  }
+  red[0][bl][lane] = s1; red[1][bl][lane] = s2;
+  __syncthreads();
+  if (bl == 0 && c < C) {           // sums are pre-zeroed by the caller (as for every BN-sum producer); gridDim.y adders per address
+    atomicAdd(sums + c, (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]));
+    atomicAdd(sums + C + c, (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]));
+  }
+}
+
 struct BnBwd {
   const bf16* dy; const bf16* z; const float* mean; const float* rstd; const float* scale; const float* shift;
   const float* gate; const float* dsq; int hw; int act; int P; int C; float inv_hw; FastDiv d_hw;
@@ -996,16 +1112,37 @@ extern "C" int mmsim_pool_bn_act(const void* z, const float* scale, const float*
   MMSIM_REQUIRE(z && scale && shift && out && B > 0 && HW > 0, "pool_bn_act: bad arguments"); REQ_C8(C, "pool_bn_act");
   // large feature maps: split the HW range over blockIdx.z so that more than B blocks stream (few adders per output)
   int nz = 1;
-  const int nr = nr_of(C);
-  while (nz < 16 && HW / (nz * 2) >= 4 * nr && B * nz < 2048) nz *= 2;
+  const int nr = pool_nr(C), gy = pool_grid_y(C);
+  while (nz < 16 && HW / (nz * 2 * nr) >= 16 && B * gy * nz < 2048) nz *= 2;      // >= 16 rows per row lane and z-slice: a slice costs 8 C atomics
   const int rpz = (HW + nz - 1) / nz;
   if (nz > 1) (void)hipMemsetAsync(out, 0, (size_t)B * C * sizeof(float), (hipStream_t)stream);
-  hipLaunchKernelGGL(pool_bn_act_kernel, dim3(B, cg_grid_y(C), nz), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scale, shift,
+  hipLaunchKernelGGL(pool_bn_act_kernel, dim3(B, gy, nz), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scale, shift,
                      (const bf16*)other, out, HW, C, act_silu, mul, rpz);
   return mmsim_check_launch("pool_bn_act");
 }
 
 /* weT: scratch [RD][C] receiving conv_expand.weight transposed (reused by the backward of the same step) */
+extern "C" int mmsim_pool_bn_bwd(const void* z, const float* scale, const float* shift, const float* mean, const float* rstd,
+                                 const void* dy, float* out5, int B, int HW, int C, void* stream) {
+  MMSIM_REQUIRE(z && scale && shift && mean && rstd && dy && out5 && B > 0 && HW > 0, "pool_bn_bwd: bad arguments"); REQ_C8(C, "pool_bn_bwd");
+  const int nr = pool_nr(C), gy = pool_grid_y(C);
+  int nz = 1;
+  while (nz < 16 && HW / (nz * 2 * nr) >= 16 && B * gy * nz < 2048) nz *= 2;
+  const int rpz = (HW + nz - 1) / nz;
+  if (nz > 1) (void)hipMemsetAsync(out5, 0, (size_t)5 * B * C * sizeof(float), (hipStream_t)stream);
+  hipLaunchKernelGGL(pool_bn_bwd_kernel, dim3(B, gy, nz), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scale, shift,
+                     mean, rstd, (const bf16*)dy, out5, B, HW, C, rpz);
+  return mmsim_check_launch("pool_bn_bwd");
+}
+
+extern "C" int mmsim_bn_bwd_sums_from_pool(const float* out5, const float* gate, const float* dsq, float* sums, int B, int HW,
+                                           int C, void* stream) {
+  MMSIM_REQUIRE(out5 && gate && dsq && sums && B > 0 && HW > 0 && C > 0, "bn_bwd_sums_from_pool: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_sums_from_pool_kernel, dim3((C + 63) / 64, B >= 64 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, out5, gate, dsq, sums, B, C,
+                     1.0f / (float)HW);
+  return mmsim_check_launch("bn_bwd_sums_from_pool");
+}
+
 extern "C" int mmsim_se_mlp_fwd(const float* s, const float* w_reduce, const float* b_reduce, const float* w_expand,
                                 const float* b_expand, float* weT, float* hr, float* hs, float* gate, int B, int C, int RD,
                                 void* stream) {

@@ -402,9 +402,12 @@ class EfficientNet(nn.Module):
                          ops.pick_split_k(b.cout, b.mid, P_out), 1, s)
         da2g = E(P_out, b.mid)
         ops.gemm(dz3, SV(pw + ".weight", (b.cout, b.mid)), da2g, b_kmajor=False)
-        dgate = E(B, b.mid, dt=torch.float32)
-        lib.pool_bn_act(bs.z2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), da2g.data_ptr(), dgate.data_ptr(), B, Ho * Wo, b.mid,
-                        1, 1.0, s)
+        # one pass over (z2, da2g): dgate for the SE backward + the partial sums of the depthwise BN's backward statistics
+        out5 = E(5, B, b.mid, dt=torch.float32)
+        mu2, rs2 = self._bnp(st, n + "." + d_bn, 0), self._bnp(st, n + "." + d_bn, 1)
+        lib.pool_bn_bwd(bs.z2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), mu2.data_ptr(), rs2.data_ptr(), da2g.data_ptr(),
+                        out5.data_ptr(), B, Ho * Wo, b.mid, s)
+        dgate = out5[0]
         dr, ds, dweT = E(B, b.rd, dt=torch.float32), E(B, b.mid, dt=torch.float32), E(b.rd, b.mid, dt=torch.float32)
         lib.se_mlp_bwd(dgate.data_ptr(), bs.gate.data_ptr(), bs.hr.data_ptr(), bs.hs.data_ptr(), bs.s.data_ptr(),
                        V(n + ".se.conv_reduce.weight").data_ptr(), bs.weT.data_ptr(),
@@ -412,7 +415,10 @@ class EfficientNet(nn.Module):
                        G(n + ".se.conv_reduce.bias").data_ptr(), G(n + ".se.conv_expand.weight").data_ptr(),
                        G(n + ".se.conv_expand.bias").data_ptr(), B, b.mid, b.rd, s)
         dz2 = E(P_out, b.mid)
-        self._bn_bwd(st, n + "." + d_bn, da2g, bs.z2, P_out, b.mid, dz2, act=True, gate=bs.gate, dsq=ds, hw=Ho * Wo)
+        lib.bn_bwd_sums_from_pool(out5.data_ptr(), bs.gate.data_ptr(), ds.data_ptr(), self._sums(st, n + "." + d_bn, "b").data_ptr(),
+                                  B, Ho * Wo, b.mid, s)
+        self._bn_bwd(st, n + "." + d_bn, da2g, bs.z2, P_out, b.mid, dz2, act=True, gate=bs.gate, dsq=ds, hw=Ho * Wo,
+                     sums_ready=True)
         del da2g
         if not hasattr(st, "gT_all"):
             self._zero_gT(st)
