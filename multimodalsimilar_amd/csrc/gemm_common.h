@@ -9,6 +9,7 @@ struct GemmParams {
   float alpha;
   // optional operand transform (1x1 conv after BN + SiLU + squeeze-excite): x -> silu(scale[c] x + shift[c]) * gate[b, c]
   const float* xf_scale; const float* xf_shift; const float* xf_gate; int xf_hw, xf_C; FastDiv xf_dhw;
+  int band;       // gemm_pp64_kernel: tile-rows per band of the tile walk
   float* stats;   // gemm_bf16_kernel, bf16 output, no split: per-M-tile column sum / sumsq slab [tiles_m][2][N] (NULL = off)
   int dbg;   // ablation switches for tools/bench_gemm.py (MMSIM_GEMM_DBG): 1 no DMA, 2 no LDS reads, 4 no MFMA; 0 in production
 };

@@ -481,7 +481,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   const int split = wg / ntiles, tile = wg - split * ntiles;
-  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  // Tiles are walked in bands of p.band tile-rows, column by column inside a band: the ~32 tiles an XCD runs at once then
+  // share band A panels (which stay in its 4-MiB L2 for the whole band) and 32/band B panels, instead of one tile-row
+  // streaming every B panel through L2 (row-major order: PMC FETCH_SIZE was 5x the operand bytes on the QKV product).
+  const int band = tile / (p.band * p.tiles_n), within = tile - band * (p.band * p.tiles_n);
+  const int rows = min(p.band, p.tiles_m - band * p.band);
+  const int tn = within / rows, tm = band * p.band + (within - tn * rows);
   const int m0 = tm * GBM, n0 = tn * BN;
   const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
@@ -629,6 +634,11 @@ static void launch_pipe(GemmParams p, int trans_a, int b_kmajor, int splits, hip
   else if (!trans_a && !b_kmajor) hipLaunchKernelGGL((KERNEL<false, false, BN>), grid, block, lds, s, p);            \
   else if (trans_a && !b_kmajor) hipLaunchKernelGGL((KERNEL<true, false, BN>), grid, block, lds, s, p);              \
   else hipLaunchKernelGGL((KERNEL<true, true, BN>), grid, block, lds, s, p);
+  {
+    static int band = -1;            // MMSIM_GEMM_BAND: tile-rows per band of the pp64 tile walk (1 = row-major)
+    if (band < 0) { const char* e = getenv("MMSIM_GEMM_BAND"); band = e ? atoi(e) : 8; if (band < 1) band = 1; }
+    p.band = band;
+  }
   if (pp >= 2) { LAUNCH(gemm_pp64_kernel) } else if (pp == 1) { LAUNCH(gemm_pp_kernel) } else { LAUNCH(gemm_fast256_kernel) }
 #undef LAUNCH
 }
