@@ -56,6 +56,20 @@ def _goes_to_pp64_nt(a, b, c, trans_a, b_kmajor, kw):
     return M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and (M // 256) * (N // 256) >= 128 and c.stride(0) % 4 == 0
 
 
+def _pmc_traffic(config):
+    """HBM-side bytes per launch of the dominant kernel (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured in separate
+    rocprofv3 --pmc passes over the same four forward shapes (tools/pmc_gemm.py) and committed under profiles/; counters
+    cannot be read inside this process, so the figure is only reported for the workload it was measured on (cfg4 / cfg3)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_gemm_pp64.json")
+    if config not in ("cfg4", "cfg3") or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    return {"hbm_bytes_per_launch": d["mean_hbm_bytes_per_launch"],
+            "algorithmic_bytes_per_launch": sum(r["algorithmic_bytes"] for r in d["per_shape"]) / len(d["per_shape"]),
+            "source": "profiles/r01_pmc_gemm_pp64.json"}
+
+
 class GemmTimer:
     """HIP events around every launch of the dominant kernel, gemm_pp64_kernel<false,true,256> (Y = X W^T), on the
     launch stream (torch's current stream is the stream the C ABI launches on)."""
@@ -200,6 +214,25 @@ def main():
     model.classifier.check_labels()
     lossv = float(loss.item())
 
+    # The towers overlap on two HIP streams inside the timed region, so the dominant kernel's launches above share the CUs
+    # with image-tower kernels.  Its rate with the chip to itself is measured right after, outside the timed region
+    # (2 untimed steps with both towers on one stream); reported as roofline.achieved_exclusive, never as `achieved`.
+    g_excl = None
+    if cfg["kind"] == "multimodal" and rank == 0 and world == 1:
+        import multimodal_classifier as _mc
+        if _mc._TWO_STREAMS:
+            g_timed, timer.rec = timer.rec, []
+            _mc._TWO_STREAMS = False
+            step.step(batch)
+            timer.on = True
+            for _ in range(2):
+                step.step(batch)
+            torch.cuda.synchronize()
+            timer.on = False
+            _mc._TWO_STREAMS = True
+            g_excl = timer.summary()
+            timer.rec = g_timed
+
     if rank == 0:
         pairs = world * cfg["batch"] * args.steps
         ms = 1e3 * elapsed / args.steps
@@ -220,7 +253,10 @@ def main():
             "roofline": None if g is None else {
                 "bound": "mfma", "kernel": "gemm_pp64_kernel<false,true,256> (Y = X W^T: 256x256 tiles, 64-deep LDS-DMA slices, ping-pong wave groups, bf16 MFMA 16x16x32, fp32 accumulate)",
                 "achieved": g["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": None, "launches": g["launches"], "avg_launch_us": g["avg_us"]},
+                "traffic": _pmc_traffic(args.config), "launches": g["launches"], "avg_launch_us": g["avg_us"],
+                "concurrent_with": "image-tower kernels on a second stream" if g_excl else None,
+                "achieved_exclusive": g_excl["tflops"] if g_excl else None,
+                "frac_exclusive": g_excl["tflops"] / MFMA_BF16_PEAK_TFLOPS if g_excl else None},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, args.cpu_steps)

@@ -13,6 +13,10 @@ from arcface import ArcMarginProduct
 from multimodalsimilar_amd.head import glue_concat
 
 
+import os
+_TWO_STREAMS = os.environ.get("MMSIM_TWO_STREAMS", "1") != "0"      # 0: both towers on the caller's stream
+
+
 def _load_tower(obj):
     if isinstance(obj, nn.Module):
         return obj
@@ -49,7 +53,34 @@ class MultimodalClassifier(nn.Module):
 
     def predict_emb(self, img_input: torch.Tensor, query_input_ids, query_token_type_ids=None, query_position_ids=None,
                     query_attention_mask=None):
-        img_embedding = self.cv.predict_emb(img_input)
-        title_embedding = self.nlp.predict_emb(query_input_ids=query_input_ids, query_token_type_ids=query_token_type_ids,
-                                               query_attention_mask=query_attention_mask)   # position ids dropped (E13)
+        # The towers are independent until the glue: the image tower runs on a second HIP stream so that its many small,
+        # latency-bound kernels (7x7 / 14x14 stages, reductions) fill in under the text tower's GEMMs.  autograd replays
+        # each tower's backward on the stream its forward ran on and orders the hand-offs, so backward overlaps as well.
+        if img_input.is_cuda and _TWO_STREAMS:
+            main = torch.cuda.current_stream(img_input.device)
+            side = self._side_stream(img_input.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                img_embedding = self.cv.predict_emb(img_input)
+            title_embedding = self.nlp.predict_emb(query_input_ids=query_input_ids, query_token_type_ids=query_token_type_ids,
+                                                   query_attention_mask=query_attention_mask)
+            main.wait_stream(side)
+            img_embedding.record_stream(main)
+            img_input.record_stream(side)
+        else:
+            img_embedding = self.cv.predict_emb(img_input)
+            title_embedding = self.nlp.predict_emb(query_input_ids=query_input_ids, query_token_type_ids=query_token_type_ids,
+                                                   query_attention_mask=query_attention_mask)   # position ids dropped (E13)
         return glue_concat(img_embedding, title_embedding)                                   # :54-56
+
+    def __getstate__(self):                 # whole-module pickles (torch.save(model)) must not carry the stream handle
+        d = self.__dict__.copy()
+        d.pop("_side", None)
+        return d
+
+    def _side_stream(self, device):
+        s = getattr(self, "_side", None)
+        if s is None or s.device != torch.device(device):
+            s = torch.cuda.Stream(device=device)
+            object.__setattr__(self, "_side", s)          # not a module attribute: never pickled / moved
+        return s
