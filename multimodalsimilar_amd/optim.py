@@ -74,3 +74,30 @@ class FusedAdamW(torch.optim.Optimizer):
                            g["weight_decay"], self._t, self.grad_scale)
             f._shadow_version = f.master._version
         return None
+
+    # ---- checkpointing (the reference saves optimiser dicts next to the model, cv_classifier_train_daodian.py:298-306)
+    def state_dict(self):
+        """param_groups (lr / betas / ... as the schedulers left them) + step count + the exp_avg / exp_avg_sq of every flat
+        buffer, in buffer order (the order of ``collect_flat_buffers`` over the modules the optimiser was built on)."""
+        d = super().state_dict()
+        d["mmsim_step"] = self._t
+        d["mmsim_moments"] = [None if self._mv.get(id(f)) is None else tuple(t.detach().cpu().clone() for t in self._mv[id(f)])
+                              for f in self.flats]
+        return d
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        step, moments = sd.pop("mmsim_step", None), sd.pop("mmsim_moments", None)
+        super().load_state_dict(sd)
+        if step is None or moments is None:
+            raise ValueError("FusedAdamW.load_state_dict: not a FusedAdamW state (mmsim_step / mmsim_moments missing)")
+        if len(moments) != len(self.flats):
+            raise ValueError(f"FusedAdamW.load_state_dict: {len(moments)} moment buffers for {len(self.flats)} flat buffers")
+        self._t = int(step)
+        self._mv = {}
+        for f, mv in zip(self.flats, moments):
+            if mv is None:
+                continue
+            if mv[0].numel() != f.master.numel():
+                raise ValueError("FusedAdamW.load_state_dict: moment buffer size does not match the flat parameter buffer")
+            self._mv[id(f)] = tuple(t.to(device=f.master.device, dtype=torch.float32).clone() for t in mv)

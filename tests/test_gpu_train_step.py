@@ -105,3 +105,42 @@ def test_eval_forward_test_and_checkpoint_roundtrip(tmp_path):
     sd = model.state_dict()
     assert "cv.backbone.blocks.1.0.conv_pw.weight" in sd and "nlp.ptm.encoder.layer.0.attention.self.query.weight" in sd
     assert "classifier.weight" in sd and "cv.backbone.bn1.running_mean" in sd
+
+
+def test_fused_adamw_state_dict_round_trip():
+    """Optimiser checkpoint: save after two steps, restore into a fresh optimiser over an identical model,
+    and the third step (same gradients) must produce bit-identical parameters -- the update kernel is elementwise."""
+    import copy
+    from multimodalsimilar_amd import train as T
+    from multimodalsimilar_amd.optim import FusedAdamW, collect_flat_buffers
+    cfg = dict(T.CONFIGS["tiny"])
+    model = T.build_model(cfg, "cuda", seed=0, dropout=False)
+    opt = FusedAdamW(model, lr=1e-3)
+    flats = collect_flat_buffers(model)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    grads = [[torch.randn(f.master.numel(), device="cuda", generator=gen) * 1e-2 for f in flats] for _ in range(3)]
+
+    def one_step(fl, o, k):
+        o.zero_grad()
+        for f, g in zip(fl, grads[k]):
+            f.ensure_device_state()
+            f.grad.copy_(g)
+        o.step()
+
+    for k in range(2):
+        one_step(flats, opt, k)
+    sd_model = copy.deepcopy(model.state_dict())
+    sd_opt = copy.deepcopy(opt.state_dict())
+    one_step(flats, opt, 2)
+    want = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    model2 = T.build_model(cfg, "cuda", seed=1, dropout=False)
+    model2.load_state_dict(sd_model)
+    opt2 = FusedAdamW(model2, lr=1e-3)
+    opt2.load_state_dict(sd_opt)
+    assert opt2.state_dict()["mmsim_step"] == 2
+    one_step(collect_flat_buffers(model2), opt2, 2)
+    got = model2.state_dict()
+    for k, v in want.items():
+        if v.is_floating_point() and "running" not in k and "num_batches" not in k:
+            assert torch.equal(got[k], v), k
