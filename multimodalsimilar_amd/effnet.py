@@ -229,6 +229,22 @@ class EfficientNet(nn.Module):
         st = self._run_forward(x)
         return st.pooled.clone()
 
+    # ---- deferred launch: the two-tower model wants this tower's autograd node created BEFORE the text tower's (autograd
+    # then replays the text backward first, whose few long GEMM launches let the host run ahead) but its forward kernels
+    # enqueued AFTER the text tower's (same reason, forward direction).  Between defer_launches() and flush_deferred() a
+    # training forward only creates the node and returns the (not yet written) pooled-feature tensor.
+    _defer = None
+
+    def defer_launches(self):
+        self._defer = []
+
+    def flush_deferred(self):
+        pend, self._defer = self._defer or [], None
+        with torch.no_grad():          # `out` already carries the node: an in-place write under grad mode would rebase its history
+            for x, out, holder in pend:
+                holder.st = self._run_forward(x)
+                out.copy_(holder.st.pooled)
+
     SCRATCH_FLOATS = 8 << 20      # per-block partial slabs of the channel reductions (largest need: ~5.5 M floats)
 
     def _scr(self):
@@ -491,12 +507,20 @@ class EfficientNet(nn.Module):
 class _EffFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, x):
-        st = model._run_forward(x)
-        ctx.model, ctx.st = model, st
-        return st.pooled.clone()
+        holder = SimpleNamespace(st=None)
+        ctx.model, ctx.holder = model, holder
+        if model._defer is not None:
+            # deferred launch (see EfficientNet.defer_launches): the autograd node exists now, the kernels are enqueued later
+            out = torch.empty(x.shape[0], model.arch.head, dtype=torch.float32, device=x.device)
+            model._defer.append((x, out, holder))
+            return out
+        holder.st = model._run_forward(x)
+        return holder.st.pooled.clone()
 
     @staticmethod
     def backward(ctx, dpooled):
-        ctx.model._run_backward(ctx.st, dpooled)
-        ctx.st = None
+        if ctx.holder.st is None:
+            raise MmsimError("EfficientNet: backward before flush_deferred() launched the deferred forward")
+        ctx.model._run_backward(ctx.holder.st, dpooled)
+        ctx.holder.st = None
         return None, None, None

@@ -144,3 +144,28 @@ def test_fused_adamw_state_dict_round_trip():
     for k, v in want.items():
         if v.is_floating_point() and "running" not in k and "num_batches" not in k:
             assert torch.equal(got[k], v), k
+
+
+def test_two_stream_schedule_matches_one_stream():
+    """The image tower runs on a second stream with its forward launches deferred behind the text tower's
+    (multimodal_classifier.py): the loss trajectory must match the single-stream schedule -- in particular the image
+    tower must still receive its gradient (a rebased autograd history on the deferred output once zeroed it)."""
+    from multimodalsimilar_amd import train as T
+    import multimodal_classifier as mc
+    cfg = dict(T.CONFIGS["tiny"])
+    old = mc._TWO_STREAMS
+    curves = {}
+    try:
+        for two in (False, True):
+            mc._TWO_STREAMS = two
+            model = T.build_model(cfg, "cuda", seed=0, dropout=False)
+            ts = T.TrainStep(model, cfg["kind"], num_training_steps=100)
+            batch = T.synthetic_batch(cfg, "cuda", seed=3)
+            curves[two] = [float(ts.step(batch)[0].item()) for _ in range(4)]
+            g = model.cv.backbone._flat.grad
+            assert g is not None
+    finally:
+        mc._TWO_STREAMS = old
+    for a, b in zip(curves[False], curves[True]):
+        assert abs(a - b) < 0.25, (curves[False], curves[True])
+    assert curves[True][-1] < curves[True][0] - 5.0          # both towers learn
