@@ -104,6 +104,6 @@ class MultimodalClassifier(nn.Module):
     def _side_stream(self, device):
         s = getattr(self, "_side", None)
         if s is None or s.device != torch.device(device):
-            s = torch.cuda.Stream(device=device)
+            s = torch.cuda.Stream(device=device, priority=int(os.environ.get("MMSIM_SIDE_PRIORITY", "0")))
             object.__setattr__(self, "_side", s)          # not a module attribute: never pickled / moved
         return s
