@@ -172,8 +172,68 @@ def gen_optim():
         npz(f"adamw_{tag}.npz", **rec)
 
 
+def gen_multilabel():
+    """nlp_classifier_multilabel.py: one embedding, three ArcFace heads (m = 0.4 / 0.2 / 0.1), and the weighted
+    CE sum of nlp_classifier_train_daodian_v3_dist.py:164-166.  Text-tower weights = the ones of nlp_tiny.npz (same seeds)."""
+    import nlp_classifier_multilabel as ref_ml
+    sys.path.insert(0, os.path.abspath(os.path.join(OUT, "..", "..")))
+    from oracle import bert_ref
+    c = dict(vocab_size=128, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
+             max_position_embeddings=64, B=4, S=32)
+    torch.manual_seed(7)
+    conf = BertConfig(vocab_size=c["vocab_size"], hidden_size=c["hidden_size"], num_hidden_layers=c["num_hidden_layers"],
+                      num_attention_heads=c["num_attention_heads"], intermediate_size=c["intermediate_size"],
+                      max_position_embeddings=c["max_position_embeddings"], hidden_dropout_prob=0.0,
+                      attention_probs_dropout_prob=0.0)
+    conf._attn_implementation = "eager"
+    ptm = BertModel(conf)
+    shape = bert_ref.BertShape(vocab_size=c["vocab_size"], hidden_size=c["hidden_size"], num_hidden_layers=c["num_hidden_layers"],
+                               num_attention_heads=c["num_attention_heads"], intermediate_size=c["intermediate_size"],
+                               max_position_embeddings=c["max_position_embeddings"])
+    sd0 = bert_ref.init_state(shape, seed=11)
+    g = torch.Generator().manual_seed(12)
+    for k in sd0:
+        if k.endswith("LayerNorm.weight"):
+            sd0[k] = 1.0 + 0.1 * torch.randn(sd0[k].shape, generator=g)
+        elif k.endswith(".bias"):
+            sd0[k] = 0.05 * torch.randn(sd0[k].shape, generator=g)
+    ptm.load_state_dict(sd0, strict=False)
+    C = (7, 23, 61)
+    model = ref_ml.NlpClassifierMultilabel(ptm, *C)
+    model.train()
+    g = torch.Generator().manual_seed(21)
+    heads = (model.firstcate_classifier, model.secondcate_classifier, model.tag_classifier)
+    with torch.no_grad():
+        for h, n in zip(heads, C):
+            h.weight.copy_(torch.randn(n, c["hidden_size"], generator=g) * 0.05)
+    B, S = c["B"], c["S"]
+    ids = torch.randint(0, c["vocab_size"], (B, S), generator=g)
+    tt = torch.randint(0, 2, (B, S), generator=g)
+    lens = torch.randint(S // 4, S + 1, (B,), generator=g)
+    lens[0] = S
+    mask = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).long()
+    labels = [torch.randint(0, n, (B,), generator=g) for n in C]
+    w = (1.0, 0.5, 2.0)
+    logits = model(ids, tt, None, mask, labels[0], labels[1], labels[2])
+    ce = torch.nn.CrossEntropyLoss()
+    loss = sum(wi * ce(lg, y) for wi, lg, y in zip(w, logits, labels))
+    loss.backward()
+    test_logits = model(ids, tt, None, mask, is_test=True)
+    out = dict(input_ids=ids, token_type_ids=tt, attention_mask=mask, weights=np.array(w), loss=loss,
+               pooled=model.predict_emb(ids, tt, None, mask))
+    for i, (h, y) in enumerate(zip(heads, labels)):
+        out[f"label{i}"], out[f"head{i}"], out[f"head_grad{i}"] = y, h.weight, h.weight.grad
+        out[f"logits{i}"], out[f"logits_test{i}"] = logits[i], test_logits[i]
+    grads = {n: p.grad for n, p in ptm.named_parameters() if p.grad is not None}
+    for k, v in grads.items():
+        out["gnorm::" + k] = v.norm()
+    out["g::pooler.dense.weight"] = grads["pooler.dense.weight"]
+    out["g::encoder.layer.1.output.dense.weight"] = grads["encoder.layer.1.output.dense.weight"]
+    npz("nlp_multilabel.npz", **out)
+
+
 if __name__ == "__main__":
-    gen_arcface()
-    gen_nlp()
-    gen_glue()
-    gen_optim()
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    for fn in (gen_arcface, gen_nlp, gen_glue, gen_optim, gen_multilabel):
+        if only is None or fn.__name__ == "gen_" + only:
+            fn()

@@ -84,6 +84,30 @@ def test_nlp_classifier_dropin_surface_and_pickle():
     assert abs(m.classifier.m - 0.44) < 1e-12
 
 
+def test_multilabel_classifier_dropin_surface():
+    """nlp_classifier_multilabel.py:6-53: attributes, margins, state-dict keys, pickle by module path."""
+    from nlp_classifier_multilabel import NlpClassifierMultilabel
+    from arcface import ArcMarginProduct
+    m = NlpClassifierMultilabel(_tiny(), 5, 7, 11)
+    heads = (m.firstcate_classifier, m.secondcate_classifier, m.tag_classifier)
+    assert all(isinstance(h, ArcMarginProduct) and h.in_feature == 128 and h.s == 64.0 for h in heads)
+    assert [h.out_feature for h in heads] == [5, 7, 11] and [round(h.m, 6) for h in heads] == [0.4, 0.2, 0.1]
+    keys = set(m.state_dict().keys())
+    assert {"firstcate_classifier.weight", "secondcate_classifier.weight", "tag_classifier.weight",
+            "ptm.pooler.dense.weight", "emb_layer.ptm.pooler.dense.weight"} <= keys
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)
+    assert type(m2).__module__ == "nlp_classifier_multilabel"
+    assert torch.equal(m2.tag_classifier.weight, m.tag_classifier.weight)
+    if not torch.cuda.is_available():
+        from multimodalsimilar_amd import MmsimError
+        with pytest.raises(MmsimError):
+            m(torch.zeros(2, 32, dtype=torch.long), firstcate_label=torch.zeros(2, dtype=torch.long),
+              secondcate_label=torch.zeros(2, dtype=torch.long), tag_label=torch.zeros(2, dtype=torch.long))
+
+
 def _pad(fl):
     used = 0
     for n in fl.names:

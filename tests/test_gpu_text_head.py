@@ -131,6 +131,56 @@ def test_nlp_classifier_matches_reference_golden(golden_dir, name):
     assert (logits_test.cpu() - T(d["logits_test"])).abs().max() < 1e-2
 
 
+def test_multilabel_classifier_matches_reference_golden(golden_dir):
+    """NlpClassifierMultilabel drop-in against vectors produced by running the reference module."""
+    from tests.test_oracle import nlp_state_from_golden
+    from multimodalsimilar_amd.bert import BertModel, BertConfig
+    from nlp_classifier_multilabel import NlpClassifierMultilabel
+    d = _load(golden_dir, "nlp_multilabel.npz")
+    shape, sd = nlp_state_from_golden(_load(golden_dir, "nlp_tiny.npz"), "tiny")
+    cfg = BertConfig(vocab_size=shape.vocab_size, hidden_size=shape.hidden_size, num_hidden_layers=shape.num_hidden_layers,
+                     num_attention_heads=shape.num_attention_heads, intermediate_size=shape.intermediate_size,
+                     max_position_embeddings=shape.max_position_embeddings, hidden_dropout_prob=0.0,
+                     attention_probs_dropout_prob=0.0)
+    ptm = BertModel(cfg)
+    ptm.load_state_dict(sd)
+    C = [d[f"head{i}"].shape[0] for i in range(3)]
+    model = NlpClassifierMultilabel(ptm, *C)
+    heads = (model.firstcate_classifier, model.secondcate_classifier, model.tag_classifier)
+    assert [round(h.m, 3) for h in heads] == [0.4, 0.2, 0.1]
+    with torch.no_grad():
+        for i, h in enumerate(heads):
+            h.weight.copy_(T(d[f"head{i}"]))
+    model.to(DEV).train()
+    ids, tt, mask = (T(d[k]).to(DEV) for k in ("input_ids", "token_type_ids", "attention_mask"))
+    ys = [T(d[f"label{i}"]).to(DEV) for i in range(3)]
+    w = [float(x) for x in d["weights"]]
+    assert relerr(model.predict_emb(ids, tt, None, mask), T(d["pooled"])) < 1e-2
+    logits = model(ids, tt, None, mask, ys[0], ys[1], ys[2])
+    for i in range(3):
+        assert (logits[i].cpu() - T(d[f"logits{i}"])).abs().max() < 0.64        # 1e-2 of the 64-scale
+    test_logits = model(ids, tt, None, mask, is_test=True)
+    for i in range(3):
+        assert (test_logits[i].cpu() - T(d[f"logits_test{i}"])).abs().max() < 1e-2
+    # fused path: weighted sum of the three margin cross-entropies, as the reference's train script forms it
+    loss, preds = model.forward_loss(ids, tt, None, mask, ys[0], ys[1], ys[2], weights=w)
+    assert abs(loss.item() - float(d["loss"])) < 2e-2 * float(d["loss"])
+    for i in range(3):
+        assert torch.equal(preds[i].cpu(), T(d[f"logits{i}"]).argmax(-1))
+    loss.backward()
+    for i, h in enumerate(heads):
+        assert relerr(h.weight.grad, T(d[f"head_grad{i}"])) < 5e-2
+    named = dict(model.ptm.named_parameters())
+    for k, v in d.items():
+        if k.endswith("attention.self.key.bias"):
+            continue                                       # analytically zero (see the single-head test)
+        if k.startswith("g::"):
+            assert relerr(named[k[3:]].grad, T(v)) < 6e-2, k
+        if k.startswith("gnorm::"):
+            gn = named[k[7:]].grad.float().norm().item()
+            assert abs(gn - float(v)) < 6e-2 * float(v) + 1e-6, (k, gn, float(v))
+
+
 def test_text_tower_against_oracle_fresh_inputs():
     """cfg-1 shaped (roberta-base width, 2 layers, S=64) forward/backward vs the CPU oracle, fused loss path."""
     from oracle import bert_ref, arcface_ref

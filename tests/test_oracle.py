@@ -104,6 +104,33 @@ def test_bert_oracle_matches_reference(golden_dir, name):
             assert abs(sd[k[7:]].grad.norm().item() - float(v)) <= 2e-3 * float(v) + 1e-6, k
 
 
+def test_multilabel_oracle_matches_reference(golden_dir):
+    """nlp_classifier_multilabel.py: one embedding, three ArcFace heads (m 0.4 / 0.2 / 0.1), weighted CE sum (SURVEY 8f-3);
+    text-tower weights are nlp_tiny.npz's (same generator seeds)."""
+    d = _load(golden_dir, "nlp_multilabel.npz")
+    shape, sd = nlp_state_from_golden(_load(golden_dir, "nlp_tiny.npz"), "tiny")
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pooled = bert_ref.bert_forward(sd, shape, T(d["input_ids"]), T(d["token_type_ids"]), T(d["attention_mask"]))
+    assert torch.allclose(pooled, T(d["pooled"]), atol=2e-5)
+    heads = [T(d[f"head{i}"]).requires_grad_(True) for i in range(3)]
+    loss = 0.0
+    for i, m in enumerate((0.4, 0.2, 0.1)):
+        z = arcface_ref.arcface_forward(pooled, heads[i], T(d[f"label{i}"]), 64.0, m, False)
+        assert torch.allclose(z, T(d[f"logits{i}"]), atol=2e-3)
+        assert torch.allclose(arcface_ref.arcface_forward_test(pooled, heads[i]), T(d[f"logits_test{i}"]), atol=1e-5)
+        loss = loss + float(d["weights"][i]) * arcface_ref.ce_loss(z, T(d[f"label{i}"]))
+    assert abs(loss.item() - float(d["loss"])) < 2e-3
+    loss.backward()
+    for i in range(3):
+        assert torch.allclose(heads[i].grad, T(d[f"head_grad{i}"]), rtol=1e-2, atol=1e-5)
+    for k, v in d.items():
+        if k.startswith("g::"):
+            ref = T(v)
+            assert (sd[k[3:]].grad - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-6, k
+        if k.startswith("gnorm::"):
+            assert abs(sd[k[7:]].grad.norm().item() - float(v)) <= 2e-3 * float(v) + 1e-6, k
+
+
 @pytest.mark.parametrize("tag", ["emb", "fc"])
 def test_adamw_linear_schedule_matches_reference(golden_dir, tag):
     d = _load(golden_dir, f"adamw_{tag}.npz")
