@@ -578,41 +578,7 @@ __global__ __launch_bounds__(256) DW_OCC void dwconv_fwd_kernel(const bf16* __re
       for (int j = 0; j < TW; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
-      if constexpr (V == 2) {            // batches of up to 3 kernel rows in flight (K = 5: 3 + 2), packed
-#pragma unroll
-        for (int kh0 = 0; kh0 < K; kh0 += 3) {
-          constexpr int RB = 3;
-          uint4 pk[RB][NIN];
-#pragma unroll
-          for (int r = 0; r < RB; ++r) {
-            const int kh = kh0 + r;
-            const int hi = ho * S - PAD + kh;
-#pragma unroll
-            for (int x = 0; x < NIN; ++x) {
-              const int wi = wo0 * S - PAD + x;
-              pk[r][x] = ld16_masked(a + (((size_t)b * g.Hi + clampi(hi, 0, g.Hi - 1)) * g.Wi + clampi(wi, 0, g.Wi - 1)) * g.C + m.cg * 8,
-                                     kh < K && hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi);
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < RB; ++r) {
-            const int kh = kh0 + r;
-            if (kh >= K) break;
-#pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-              float w[8];
-              ld8f(wT + (size_t)(kh * K + kw) * g.C + m.cg * 8, w);
-#pragma unroll
-              for (int j = 0; j < TW; ++j) {
-                float in[8];
-                unpack8(pk[r][j * S + kw], in);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[j][e] += in[e] * w[e];
-              }
-            }
-          }
-        }
-      } else if constexpr (V == 1) {
+      if constexpr (V == 1) {
         uint4 pk[K][NIN];
 #pragma unroll
         for (int kh = 0; kh < K; ++kh) {
@@ -1233,7 +1199,7 @@ extern "C" int mmsim_dwconv_fwd(const void* a, const float* w_tap_major, void* z
   DwGeom g; int rc = dw_check(B, Hi, Wi, C, K, S, &g); if (rc) return rc;
   MMSIM_REQUIRE(a && w_tap_major && z && sums, "dwconv_fwd: null operand");
   // V (see the kernel): packed up-front loads pay for 3x3 (2x faster, 72-96 VGPRs of loads in flight); 5x5 would need 160
-  // and is best served by the row-at-a-time form.  MMSIM_DW_VARIANT=0/1/2 forces one form (tools/bench_dw.py).
+  // and is best served by the row-at-a-time form.  MMSIM_DW_VARIANT=0/1 forces one form (tools/bench_dw.py).
   static int variant = -2;
   if (variant == -2) { const char* e = getenv("MMSIM_DW_VARIANT"); variant = e ? atoi(e) % 10 : -1; }
   const int Vv = variant >= 0 ? variant : (K == 3 ? 1 : 0);
@@ -1246,7 +1212,7 @@ extern "C" int mmsim_dwconv_fwd(const void* a, const float* w_tap_major, void* z
 #define DWF_KS(TT, VV)                                        \
   if (K == 3 && S == 1) DWF(3, 1, TT, VV); else if (K == 3 && S == 2) DWF(3, 2, TT, VV); \
   else if (K == 5 && S == 1) DWF(5, 1, TT, VV); else DWF(5, 2, TT, VV);
-  if (Vv == 1) { DWF_KS(4, 1) } else if (Vv == 2) { DWF_KS(4, 2) } else { DWF_KS(4, 0) }
+  if (Vv == 1) { DWF_KS(4, 1) } else { DWF_KS(4, 0) }
 #undef DWF_KS
 #undef DWF
   launch_reduce(scratch, grid.x, 2 * C, sums, 1, (hipStream_t)stream);

@@ -1,7 +1,10 @@
-// Fast path of the bf16 MFMA GEMM for tile-aligned shapes (the text tower): 256x128x64 tiles, 512 threads = 8 waves
-// (4 along M x 2 along N, 64x64 each), operands brought HBM -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no
-// VGPR staging), a 3-slot LDS ring with TWO K-tiles in flight behind a counted s_waitcnt vmcnt and ONE raw s_barrier
-// per K-step (cdna_hip_programming.md section 5, "Pipelining across barriers" / "3-buf span").
+// Fast paths of the bf16 MFMA GEMM for tile-aligned shapes (the text tower and the ArcFace head), operands brought
+// HBM -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPR staging):
+//   gemm_pp64_kernel  256 x 256 (or 256 x 128) tiles, 64-deep slices, two wave groups in anti-phase -- the production
+//                     kernel (described in front of it);
+//   gemm_fast_kernel  256 x 128 x 64 tiles, 3-slot ring, ONE raw s_barrier per K-step, two K-tiles in flight behind a counted
+//                     s_waitcnt vmcnt (cdna_hip_programming.md section 5, "3-buf span"): kept for the wgrad-shaped products
+//                     with few output tiles (attention-output projection), where it measures faster.
 //
 // LDS-DMA writes lane-linearly (wave-uniform base + lane*16), so the bank-conflict swizzle is applied to the SOURCE
 // address and undone on the read (guide rule 21):
@@ -9,8 +12,8 @@
 //                                                  -> ds_read_b128 fragments are conflict-free;
 //   transposed operand [64 k][cols] (256/512-B rows): 32-B column block cb of k-row k at block cb ^ key(k)
 //                                                  -> ds_read_b64_tr_b16 fragments are conflict-free.
-// Per step t:  wait(tile t landed: vmcnt(6) leaves tile t+1 in flight) -> s_barrier -> issue tile t+2 into the
-// slot read in step t-1 (every wave has passed the barrier, so nobody still reads it) -> 32 MFMAs per wave on tile t.
+// gemm_fast_kernel, per step t:  wait(tile t landed: vmcnt(6) leaves tile t+1 in flight) -> s_barrier -> issue tile t+2
+// into the slot read in step t-1 (every wave has passed the barrier) -> 32 MFMAs per wave on tile t.
 #include "gemm_common.h"
 #include <stdlib.h>
 
@@ -168,288 +171,26 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p) {
   else fast_epilogue<EPI_NONE, 1>(p, acc, row0, col0, lane, fs, stg);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// 256x256x32 variant: twice the arithmetic intensity of the 256x128 tile (128 flop per staged byte, the L2->LDS
-// stream is what bounds the smaller tile), 8 waves as 2 (M) x 4 (N) with 128x64 per wave (acc[8][4]), a 4-slot ring
-// of 32-KiB K-slices with THREE slices in flight, one raw s_barrier per K-step of 32 MFMAs per wave.
-// k-major rows are 64 B here: 16-B chunk c of row r is stored at c ^ G(r), G(r) = (-(r >> 2)) & 3 (conflict-free
-// for the ds_read_b128 lane groups); transposed operands use the same 32-B column-block swizzle as above.
 #define GBM 256
-#define GBN 256
-#define GBK 32
-#define G_SLOTS 4
-
-template <bool TRANS, int ROWS>      // ROWS = 256 or 128 rows (k-major) / columns (transposed) of the operand tile
-__device__ __forceinline__ void dma_tile32(const bf16* __restrict__ X, int ld, int r0, int k0, char* lds, int wave, int lane) {
-  constexpr int NI = ROWS / 128;        // 1-KiB wave-instructions per wave: the tile is ROWS*64 bytes
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int blk = wave * NI + i;
-    const bf16* src;
-    if (!TRANS) {
-      const int row = blk * 16 + (lane >> 2), pos = lane & 3;
-      const int c = pos ^ ((-(row >> 2)) & 3);
-      src = X + (size_t)(r0 + row) * ld + k0 + c * 8;
-    } else {
-      constexpr int CPR = ROWS / 8;      // 16-B chunks per k-row (32 or 16); a 1-KiB block holds 64 / CPR k-rows
-      const int k = blk * (64 / CPR) + lane / CPR, pc = lane % CPR;
-      const int c = (((pc >> 1) ^ ftr_key(k)) << 1) | (pc & 1);
-      src = X + (size_t)(k0 + k) * ld + r0 + c * 8;
-    }
-    __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(lds + blk * 1024), 16, 0, 0);
-  }
-}
-
-template <bool TRANS, int ROWS>
-__device__ __forceinline__ bf8 gfrag(const char* lds, int rbase, int lane) {
-  if (!TRANS) {
-    const int row = rbase + (lane & 15), kc = lane >> 4;
-    return ds_read_b128_asm(lds + row * 64 + ((kc ^ ((-(row >> 2)) & 3)) << 4));
-  } else {
-    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    const int k = 8 * g + q;
-    const int off = k * (ROWS * 2) + (((rbase >> 4) ^ ftr_key(k)) << 5) + p * 8;
-    return tr_read_pair_asm<4 * ROWS * 2>(lds + off);
-  }
-}
-
-template <bool TA, bool TB_KMAJOR, int BN>     // BN = 256: 2 x 4 waves of 128 x 64;  BN = 128: 4 x 2 waves of 64 x 64
-__global__ __launch_bounds__(512, 2) void gemm_fast256_kernel(GemmParams p) {
-  constexpr int MT = BN == 256 ? 8 : 4;                  // 16-row MFMA tiles per wave along M
-  constexpr int WROWS = MT * 16;
-  constexpr int A_BYTES = GBM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
-  constexpr int LPS = 2 + BN / 128;                      // LDS-DMA instructions per wave per K-slice
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = BN == 256 ? (wave >> 2) : (wave >> 1), wn = BN == 256 ? (wave & 3) : (wave & 1);
-
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int nwg = ntiles * p.splits;
-  const int bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  const int split = wg / ntiles, tile = wg - split * ntiles;
-  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-  const int m0 = tm * GBM, n0 = tn * BN;
-  const int kbeg = split * p.k_per_split;
-  const int kend = min(p.K, kbeg + p.k_per_split);
-  const int nk = (kend - kbeg) / GBK;
-
-  f4 acc[MT][4];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
-
-  // Software pipeline (per K-slice t):  slice t lives in REGISTERS (fragment set A), slices t+1..t+3 are in the LDS
-  // ring or in flight, and the step reads slice t+1's fragments into set B while the MFMAs of slice t run, so
-  // neither the LDS-read latency nor the DMA latency sits on the MFMA critical path.  Because a slice's slot is
-  // free as soon as its fragments are in registers, the 4-slot ring keeps FOUR slices ahead of the MFMAs.
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-    if (t < nk && !(p.dbg & 1)) {
-      dma_tile32<TA, GBM>(p.A, p.lda, m0, kbeg + t * GBK, smem + t * STAGE, wave, lane);
-      dma_tile32<!TB_KMAJOR, BN>(p.B, p.ldb, n0, kbeg + t * GBK, smem + t * STAGE + A_BYTES, wave, lane);
-    }
-  bf8 afA[MT], bfA[4], afB[MT], bfB[4];
-  {
-    const int ahead = min(nk - 1, 3);                    // slices issued after slice 0
-    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
-    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bfA[j] = gfrag<!TB_KMAJOR, BN>(smem + A_BYTES, wn * 64 + j * 16, lane);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) afA[i] = gfrag<TA, GBM>(smem, wm * WROWS + i * 16, lane);
-  }
-  // one pipeline step: consume (af0, bf0) = slice t, fill (af1, bf1) with slice t+1, refill the ring with slice t+4
-#define GEMM256_STEP(af0, bf0, af1, bf1, T)                                                                         \
-  {                                                                                                                 \
-    const int t_ = (T);                                                                                             \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* slice t's fragments (asm + compiler LDS reads) landed */ \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    if (t_ + 1 < nk) {                                                                                              \
-      const int ahead = min(nk - 2 - t_, 2);           /* slices issued after slice t+1 */                        \
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");                                \
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");                               \
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
-      __builtin_amdgcn_s_barrier();                                                                                 \
-      __builtin_amdgcn_sched_barrier(0);                                                                            \
-      if (t_ + 4 < nk && !(p.dbg & 1)) {                                                                            \
-        char* ns = smem + (t_ & 3) * STAGE;            /* slot of slice t: its fragments are in registers */        \
-        dma_tile32<TA, GBM>(p.A, p.lda, m0, kbeg + (t_ + 4) * GBK, ns, wave, lane);                                 \
-        dma_tile32<!TB_KMAJOR, BN>(p.B, p.ldb, n0, kbeg + (t_ + 4) * GBK, ns + A_BYTES, wave, lane);                \
-      }                                                                                                             \
-      const char* la = smem + ((t_ + 1) & 3) * STAGE;                                                               \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) bf1[j] = gfrag<!TB_KMAJOR, BN>(la + A_BYTES, wn * 64 + j * 16, lane); \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i) af1[i] = gfrag<TA, GBM>(la, wm * WROWS + i * 16, lane);        \
-    }                                                                                                               \
-    if (!(p.dbg & 4)) {                                                                                             \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j], af0[i], acc[i][j], 0, 0, 0);                  \
-    }                                                                                                               \
-  }
-  for (int t = 0; t < nk; t += 2) {
-    GEMM256_STEP(afA, bfA, afB, bfB, t)
-    if (t + 1 < nk) GEMM256_STEP(afB, bfB, afA, bfA, t + 1)
-  }
-#undef GEMM256_STEP
-  const bool fs = split == 0;
-  float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
-  if (p.dbg & 8) {                  // ablation: keep the accumulators live but skip the staged epilogue
-    float sacc = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (sacc == 12345.678f) reinterpret_cast<float*>(p.C)[0] = sacc;
-    return;
-  }
-#pragma unroll
-  for (int half = 0; half < MT / 4; ++half) {
-    __syncthreads();          // ring (first pass) / previous staging pass fully consumed
-    f4 (&a4)[4][4] = *reinterpret_cast<f4 (*)[4][4]>(&acc[half * 4][0]);
-    const int row0 = m0 + wm * WROWS + half * 64, col0 = n0 + wn * 64;
-    if (!p.c_f32) fast_epilogue_epi<0>(p, a4, row0, col0, lane, fs, stg);
-    else if (p.atomic) fast_epilogue<EPI_NONE, 3>(p, a4, row0, col0, lane, fs, stg);
-    else if (p.accum) fast_epilogue<EPI_NONE, 2>(p, a4, row0, col0, lane, fs, stg);
-    else if (p.epi == EPI_TANH) fast_epilogue<EPI_TANH, 1>(p, a4, row0, col0, lane, fs, stg);
-    else fast_epilogue<EPI_NONE, 1>(p, a4, row0, col0, lane, fs, stg);
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------
-// Ping-pong form of the 256 x BN x 32 kernel.  The eight waves are two groups of four (waves w and w+4 share a SIMD);
-// every K-step of a wave is  [barrier] LOAD phase: fragments of slice t from LDS -> registers, LDS-DMA of slice t+3,
-// counted waits  [barrier] COMPUTE phase: 32 MFMAs at raised priority.  Group 1 executes one extra barrier before its
-// loop, so the groups run in anti-phase: while one wave of a SIMD issues its MFMAs back to back, its partner issues
-// DMA descriptors and LDS reads -- in the single-barrier form above both waves of a SIMD reach their ~500-cycle
-// load section together and the matrix pipe idles through it (measured: DMA+reads alone and MFMA alone each took as
-// long as 70 % of the full loop).  One fragment set suffices (the partner's MFMAs, not this wave's, hide the reads).
-//   RAW: every wave waits (vmcnt) for slice t+1 at the END of load phase t, i.e. before a barrier that every reader of
-//        slice t+1 passes before its load phase t+1 (group 0: B1(t+1) = group 1's B2(t); group 1: B1(t+1) = group 0's B2(t+1)).
-//   WAR: slice t+3 goes to the slot of slice t-1, whose reads every wave retired (lgkmcnt(0)) before ITS B2(t-1); a
-//        group-0 wave issues after B1(t) (= group 1's B2(t-1)), a group-1 wave after its B1(t) (= group 0's B2(t)).
-template <bool TA, bool TB_KMAJOR, int BN>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
-  constexpr int MT = BN == 256 ? 8 : 4;
-  constexpr int WROWS = MT * 16;
-  constexpr int A_BYTES = GBM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
-  constexpr int LPS = 2 + BN / 128;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = BN == 256 ? (wave >> 2) : (wave >> 1), wn = BN == 256 ? (wave & 3) : (wave & 1);
-  const int grp = wave >> 2;
-
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int nwg = ntiles * p.splits;
-  const int bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  const int split = wg / ntiles, tile = wg - split * ntiles;
-  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-  const int m0 = tm * GBM, n0 = tn * BN;
-  const int kbeg = split * p.k_per_split;
-  const int kend = min(p.K, kbeg + p.k_per_split);
-  const int nk = (kend - kbeg) / GBK;
-
-  f4 acc[MT][4];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-    if (t < nk && !(p.dbg & 1)) {
-      dma_tile32<TA, GBM>(p.A, p.lda, m0, kbeg + t * GBK, smem + t * STAGE, wave, lane);
-      dma_tile32<!TB_KMAJOR, BN>(p.B, p.ldb, n0, kbeg + t * GBK, smem + t * STAGE + A_BYTES, wave, lane);
-    }
-  {
-    const int ahead = min(nk - 1, 2);                    // slices issued after slice 0
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  if (grp == 1) __builtin_amdgcn_s_barrier();            // the anti-phase offset
-  bf8 af[MT], bfr[4];
-  for (int t = 0; t < nk; ++t) {
-    __builtin_amdgcn_s_barrier();                        // B1
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      const char* la = smem + (t & 3) * STAGE;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = gfrag<!TB_KMAJOR, BN>(la + A_BYTES, wn * 64 + j * 16, lane);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = gfrag<TA, GBM>(la, wm * WROWS + i * 16, lane);
-    }
-    if (t + 3 < nk && !(p.dbg & 1)) {
-      char* ns = smem + ((t + 3) & 3) * STAGE;
-      dma_tile32<TA, GBM>(p.A, p.lda, m0, kbeg + (t + 3) * GBK, ns, wave, lane);
-      dma_tile32<!TB_KMAJOR, BN>(p.B, p.ldb, n0, kbeg + (t + 3) * GBK, ns + A_BYTES, wave, lane);
-    }
-    {
-      const int ahead = min(nk - 1, t + 3) - (t + 1);   // slices that may stay in flight behind slice t+1
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                        // B2
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(p.dbg & 4)) {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();            // both groups have now executed 2 nk + 1 barriers
-  const bool fs = split == 0;
-  float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
-  if (p.dbg & 8) {
-    float sacc = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (sacc == 12345.678f) reinterpret_cast<float*>(p.C)[0] = sacc;
-    return;
-  }
-#pragma unroll
-  for (int half = 0; half < MT / 4; ++half) {
-    __syncthreads();
-    f4 (&a4)[4][4] = *reinterpret_cast<f4 (*)[4][4]>(&acc[half * 4][0]);
-    const int row0 = m0 + wm * WROWS + half * 64, col0 = n0 + wn * 64;
-    if (!p.c_f32) fast_epilogue_epi<0>(p, a4, row0, col0, lane, fs, stg);
-    else if (p.atomic) fast_epilogue<EPI_NONE, 3>(p, a4, row0, col0, lane, fs, stg);
-    else if (p.accum) fast_epilogue<EPI_NONE, 2>(p, a4, row0, col0, lane, fs, stg);
-    else if (p.epi == EPI_TANH) fast_epilogue<EPI_TANH, 1>(p, a4, row0, col0, lane, fs, stg);
-    else fast_epilogue<EPI_NONE, 1>(p, a4, row0, col0, lane, fs, stg);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Ping-pong kernel with 64-deep K-slices: the same anti-phase schedule, but an LDS-DMA wave-instruction now moves
-// 8 rows x 128 B (whole cache lines) instead of 16 rows x 64 B -- the texture-address path prices an instruction by the
-// lines it touches, and with 64-B pieces the DMA stream alone (no MFMA) ran at 11.5 TB/s chip-wide, slower than the
-// MFMAs it has to feed.  LDS (160 KiB, all of it): A ring 3 x 32 KiB (the streamed operand: its next slice is issued
-// three steps before it is read, enough for an HBM miss) + B ring 2 x (BN x 128 B).  A 64-deep slice is consumed in two
+// Ping-pong kernel with 64-deep K-slices (the production path for tile-aligned products).
+// 256 x BN output tiles, 8 waves (BN = 256: 2 x 4 waves of 128 x 64; BN = 128: 4 x 2 waves of 64 x 64), operands by
+// LDS-DMA.  The eight waves are two groups of four (waves w and w+4 share a SIMD) running in ANTI-PHASE: group 1 executes
+// one extra barrier before its loop, so while one wave of a SIMD issues its 32 MFMAs back to back (raised priority) its
+// partner issues LDS reads and DMA descriptors.  With a single barrier per step both waves of a SIMD reach their ~500-cycle
+// load section together and the matrix pipe idles through it (measured with the 32-deep predecessors of this kernel:
+// single barrier 930, anti-phase 978, anti-phase + 64-deep slices 1056 TFLOP/s on the text shapes).
+// A 64-deep slice makes every LDS-DMA wave-instruction move 8 rows x 128 B (whole cache lines) instead of 16 rows x 64 B:
+// the texture-address path prices an instruction by the lines it touches, and with 64-B pieces the DMA stream alone (no
+// MFMA) ran at 11.5 TB/s chip-wide, slower than the MFMAs it has to feed.
+// LDS (160 KiB, all of it): A ring 3 x 32 KiB (the streamed operand: its next slice is issued three steps before it is
+// read, enough for an HBM miss) + B ring 2 x (BN x 128 B).  A 64-deep slice is consumed in two
 // 32-deep steps (one fragment set, 32 MFMAs per wave each):
 //   even step 2u:   B1 | read k-half 0 of slice u; issue B_{u+1};                      lgkmcnt(0) | B2 | MFMAs
 //   odd  step 2u+1: B1 | read k-half 1 of slice u; issue A_{u+2}; vmcnt(|A_{u+2}|);    lgkmcnt(0) | B2 | MFMAs
 // Per-wave issue order is A0 B0 A1 | B1 A2 | B2 A3 | ..., so "all but the youngest A unit" at the end of an odd step
-// means slice u+1 (A_{u+1}, B_{u+1}) has landed.  RAW / WAR arguments as for gemm_pp_kernel: a unit is waited for at the
+// means slice u+1 (A_{u+1}, B_{u+1}) has landed.  RAW / WAR: a unit is waited for at the
 // end of the load phase BEFORE the one that first reads it, and a slot is refilled in the load phase AFTER the one
 // that last read it (B_{u+1} -> slot of B_{u-1}, last read in step 2u-1; A_{u+2} -> slot of A_{u-1}, same).
 template <bool TRANS, int ROWS>
@@ -601,46 +342,30 @@ static int tile_pref() {      // MMSIM_GEMM_TILE: 0 auto (default), 1 = old 256x
   return v;
 }
 
-// MMSIM_GEMM_PP: 2 (default) ping-pong with 64-deep slices, 1 ping-pong with 32-deep slices, 0 the single-barrier form
-static int pp_pref() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MMSIM_GEMM_PP"); v = e ? atoi(e) : 2; }
-  return v;
-}
-
 template <int BN>
 static void launch_pipe(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s) {
   p.tiles_m = p.M / GBM; p.tiles_n = p.N / BN; p.splits = splits;
   dim3 grid(p.tiles_m * p.tiles_n * splits), block(512);
-  // 136 KiB: epilogue staging (8 waves x 64 x 68 floats) >= the 32-deep operand rings; 160 KiB: the 64-deep rings
-  const int pp = pp_pref();
-  const size_t lds_stage = 8 * 64 * EP_PITCH * 4, lds_ring64 = 3 * GBM * 128 + 2 * BN * 128;
-  const size_t lds = (pp >= 2 && lds_ring64 > lds_stage) ? lds_ring64 : lds_stage;
+  // 160 KiB: A ring 3 x 32 KiB + B ring 2 x (BN x 128 B); never less than the epilogue staging (8 waves x 64 x 68 floats)
+  const size_t lds_stage = 8 * 64 * EP_PITCH * 4, lds_ring = 3 * GBM * 128 + 2 * BN * 128;
+  const size_t lds = lds_ring > lds_stage ? lds_ring : lds_stage;
   static bool done = false;
   if (!done) {
-    const size_t lds64 = 3 * GBM * 128 + 2 * BN * 128, lds32 = 8 * 64 * EP_PITCH * 4;
-#define SET_LDS(KERNEL)                                                                                              \
-    (void)hipFuncSetAttribute((const void*)KERNEL<false, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-    (void)hipFuncSetAttribute((const void*)KERNEL<false, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    (void)hipFuncSetAttribute((const void*)KERNEL<true, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-    (void)hipFuncSetAttribute((const void*)KERNEL<true, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    { const size_t lds = lds32; SET_LDS(gemm_fast256_kernel) SET_LDS(gemm_pp_kernel) }
-    { const size_t lds = lds64 > lds32 ? lds64 : lds32; SET_LDS(gemm_pp64_kernel) }
-#undef SET_LDS
+    (void)hipFuncSetAttribute((const void*)gemm_pp64_kernel<false, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_pp64_kernel<false, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_pp64_kernel<true, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_pp64_kernel<true, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     done = true;
   }
-#define LAUNCH(KERNEL)                                                                                               \
-  if (!trans_a && b_kmajor) hipLaunchKernelGGL((KERNEL<false, true, BN>), grid, block, lds, s, p);                   \
-  else if (!trans_a && !b_kmajor) hipLaunchKernelGGL((KERNEL<false, false, BN>), grid, block, lds, s, p);            \
-  else if (trans_a && !b_kmajor) hipLaunchKernelGGL((KERNEL<true, false, BN>), grid, block, lds, s, p);              \
-  else hipLaunchKernelGGL((KERNEL<true, true, BN>), grid, block, lds, s, p);
   {
-    static int band = -1;            // MMSIM_GEMM_BAND: tile-rows per band of the pp64 tile walk (1 = row-major)
+    static int band = -1;            // MMSIM_GEMM_BAND: tile-rows per band of the tile walk (1 = row-major)
     if (band < 0) { const char* e = getenv("MMSIM_GEMM_BAND"); band = e ? atoi(e) : 8; if (band < 1) band = 1; }
     p.band = band;
   }
-  if (pp >= 2) { LAUNCH(gemm_pp64_kernel) } else if (pp == 1) { LAUNCH(gemm_pp_kernel) } else { LAUNCH(gemm_fast256_kernel) }
-#undef LAUNCH
+  if (!trans_a && b_kmajor) hipLaunchKernelGGL((gemm_pp64_kernel<false, true, BN>), grid, block, lds, s, p);
+  else if (!trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_pp64_kernel<false, false, BN>), grid, block, lds, s, p);
+  else if (trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_pp64_kernel<true, false, BN>), grid, block, lds, s, p);
+  else hipLaunchKernelGGL((gemm_pp64_kernel<true, true, BN>), grid, block, lds, s, p);
 }
 
 void gemm_fast_launch(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s) {
