@@ -298,8 +298,7 @@ class BertModel(nn.Module):
                        m.ph, m.seed, 4 * li + 2)
             ops.gemm(dT, ws.u[li], G(p + "output.dense.weight"), trans_a=True, b_kmajor=False, split_k=skI, accumulate=True)
             ops.gemm(dT, SV(p + "output.dense.weight"), ws.du, b_kmajor=False, epilogue=ops.EPI_MUL_GELU_GRAD,
-                     aux_in=ws.upre[li])
-            ops.colsum(ws.du, G(p + "intermediate.dense.bias"))
+                     aux_in=ws.upre[li], colsum=G(p + "intermediate.dense.bias"))      # dX + the bias gradient in one launch
             ops.gemm(ws.du, ws.h1[li], G(p + "intermediate.dense.weight"), trans_a=True, b_kmajor=False, split_k=skI,
                      accumulate=True)
             ops.gemm(ws.du, SV(p + "intermediate.dense.weight"), ws.dhb, b_kmajor=False)
