@@ -72,6 +72,12 @@ int mmsim_attn_fwd(const void* qkv, int ld_qkv, const long long* mask, void* ctx
 int mmsim_attn_bwd(const void* qkv, int ld_qkv, const long long* mask, const void* ctx, const void* dctx, int ld_ctx,
                    const float* lse, void* dqkv, int B, int S, int heads, int H, float dropout_p,
                    unsigned long long seed, unsigned int stream_id, void* stream);
+/* mmsim_attn_bwd that also accumulates dbias [3H] += dqkv.sum(0) (bias gradients of the fused q|k|v projection, of the
+ * rounded values) without re-reading dqkv.  scratch: >= B * 3H floats. */
+int mmsim_attn_bwd_dbias(const void* qkv, int ld_qkv, const long long* mask, const void* ctx, const void* dctx, int ld_ctx,
+                         const float* lse, void* dqkv, float* dbias, int B, int S, int heads, int H, float dropout_p,
+                         unsigned long long seed, unsigned int stream_id, float* scratch, unsigned long long scratch_floats,
+                         void* stream);
 
 /* ---- BERT embeddings: LayerNorm(word[ids] + type[tt] + pos[0..S)) then dropout (modeling_bert.py:68-108).
  * ids / token_types: int64 [B*S] (token_types may be NULL = zeros); tables and gamma/beta fp32; out bf16 [B*S,H].

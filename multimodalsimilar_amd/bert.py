@@ -15,6 +15,7 @@ Gradients are written straight into the flat gradient buffer (parameter ``.grad`
 import math
 from types import SimpleNamespace
 
+import os
 import torch
 import torch.nn as nn
 
@@ -22,6 +23,9 @@ from . import ops
 from .flat import FlatBuffer
 from ._lib import MmsimError
 
+
+_FUSE = int(os.environ.get("MMSIM_FUSE_BIAS_GRADS", "1"))      # 0 separate column-sum passes, 1 both fused, 2 GEMM only, 3 attention only
+_FUSE_GEMM_BIAS, _FUSE_ATTN_BIAS = _FUSE in (1, 2), _FUSE in (1, 3)
 
 class BertConfig:
     """The subset of HF BertConfig the tower needs (defaults: hfl/chinese-roberta-wwm-ext)."""
@@ -298,7 +302,9 @@ class BertModel(nn.Module):
                        m.ph, m.seed, 4 * li + 2)
             ops.gemm(dT, ws.u[li], G(p + "output.dense.weight"), trans_a=True, b_kmajor=False, split_k=skI, accumulate=True)
             ops.gemm(dT, SV(p + "output.dense.weight"), ws.du, b_kmajor=False, epilogue=ops.EPI_MUL_GELU_GRAD,
-                     aux_in=ws.upre[li], colsum=G(p + "intermediate.dense.bias"))      # dX + the bias gradient in one launch
+                     aux_in=ws.upre[li], colsum=G(p + "intermediate.dense.bias") if _FUSE_GEMM_BIAS else None)      # dX + bias gradient
+            if not _FUSE_GEMM_BIAS:
+                ops.colsum(ws.du, G(p + "intermediate.dense.bias"))
             ops.gemm(ws.du, ws.h1[li], G(p + "intermediate.dense.weight"), trans_a=True, b_kmajor=False, split_k=skI,
                      accumulate=True)
             ops.gemm(ws.du, SV(p + "intermediate.dense.weight"), ws.dhb, b_kmajor=False)
@@ -313,8 +319,11 @@ class BertModel(nn.Module):
                      accumulate=True)
             ops.gemm(dT, SV(p + "attention.output.dense.weight"), ws.dctx, b_kmajor=False)
             # ---- attention
-            ops.attn_bwd(ws.qkv[li], m.mask, ws.ctx[li], ws.dctx, ws.lse[li], ws.dqkv, B, S, nh, H, m.pa, m.seed, 4 * li + 3)
-            ops.colsum(ws.dqkv, fl._view(fl.grad, p + "attention.self.query.bias", (3 * H,)))
+            qkv_db = fl._view(fl.grad, p + "attention.self.query.bias", (3 * H,))
+            ops.attn_bwd(ws.qkv[li], m.mask, ws.ctx[li], ws.dctx, ws.lse[li], ws.dqkv, B, S, nh, H, m.pa, m.seed, 4 * li + 3,
+                         dbias=qkv_db if _FUSE_ATTN_BIAS else None)                               # + the q|k|v bias gradients
+            if not _FUSE_ATTN_BIAS:
+                ops.colsum(ws.dqkv, qkv_db)
             ops.gemm(ws.dqkv, ws.h[li], fl._view(fl.grad, p + "attention.self.query.weight", (3 * H, H)), trans_a=True,
                      b_kmajor=False, split_k=sk3, accumulate=True)
             nxt = ws.dh[1] if dh is ws.dh[0] else ws.dh[0]

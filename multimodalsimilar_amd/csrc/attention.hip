@@ -17,6 +17,7 @@
 
 struct AttnParams {
   const bf16* qkv; const int64_t* mask; bf16* ctx; const bf16* dctx; float* lse; bf16* dqkv;
+  float* dbias_parts;    // backward: per-batch-element column sums of dqkv, slab [B][3H] (NULL = off)
   int ld_qkv, ld_ctx, heads, H;
   float scale;
   unsigned long long seed; unsigned int stream, thresh; float inv_keep;
@@ -177,6 +178,12 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
   char* Ds = smem + 3 * S * ROW_PITCH;      // dS^T [S keys][DST_PITCH] for the current query tile
   float* fl = reinterpret_cast<float*>(smem + 3 * S * ROW_PITCH + S * DST_PITCH);
   float* lse = fl; float* dl = fl + S; float* mb = fl + 2 * S;
+  float* cb = fl + 3 * S;                   // [192] column sums of this (b, h)'s dq | dk | dv (bias gradient of the QKV projection)
+  float cq[TPW][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) cq[t][0] = cq[t][1] = cq[t][2] = cq[t][3] = 0.f;
+  if (p.dbias_parts)
+    for (int i = threadIdx.x; i < 192; i += 64 * NT) cb[i] = 0.f;       // ordered before the adds by the barriers of the loop
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5;
   const int bh = blockIdx.x, b = bh / p.heads, h = bh % p.heads;
   const bf16* base = p.qkv + (size_t)b * S * p.ld_qkv + h * 64;
@@ -293,6 +300,8 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
       const int d = 16 * d4 + (lane >> 4) * 4;
       bf4 o = {f2bf(acc[0] * p.scale), f2bf(acc[1] * p.scale), f2bf(acc[2] * p.scale), f2bf(acc[3] * p.scale)};
       *reinterpret_cast<bf4*>(p.dqkv + ((size_t)b * S + q) * p.ld_qkv + h * 64 + d) = o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cq[t][e] += bf2f(o[e]);
     }
     __syncthreads();
   }
@@ -308,7 +317,32 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
       bf4 ov = {f2bf(dV[dt][4 * g4]), f2bf(dV[dt][4 * g4 + 1]), f2bf(dV[dt][4 * g4 + 2]), f2bf(dV[dt][4 * g4 + 3])};
       *reinterpret_cast<bf4*>(dk + d) = ok;
       *reinterpret_cast<bf4*>(dv + d) = ov;
+      if (p.dbias_parts) {          // sums over this wave's 32 keys (the lanes of a half-wave), of the ROUNDED values
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float sk = bf2f(ok[e]), sv = bf2f(ov[e]);
+#pragma unroll
+          for (int o2 = 1; o2 < 32; o2 <<= 1) { sk += __shfl_xor(sk, o2, 64); sv += __shfl_xor(sv, o2, 64); }
+          if ((lane & 31) == 0) { atomicAdd(cb + 64 + d + e, sk); atomicAdd(cb + 128 + d + e, sv); }
+        }
+      }
     }
+  if (p.dbias_parts) {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {       // dq: rows of a 16x16 tile sit on lanes 0..15 of each 16-lane group
+      const int d4 = (w * TPW + t) & 3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float sq = cq[t][e];
+#pragma unroll
+        for (int o2 = 1; o2 < 16; o2 <<= 1) sq += __shfl_xor(sq, o2, 64);
+        if ((lane & 15) == 0) atomicAdd(cb + 16 * d4 + (lane >> 4) * 4 + e, sq);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 192; i += 64 * NT)
+      p.dbias_parts[(size_t)b * 3 * p.H + (i >> 6) * p.H + h * 64 + (i & 63)] = cb[i];
+  }
 }
 
 static int attn_check(int B, int S, int heads, int H, int ld_qkv, int ld_ctx, const void* qkv) {
@@ -328,6 +362,7 @@ extern "C" int mmsim_attn_fwd(const void* qkv, int ld_qkv, const long long* mask
   MMSIM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "attention: dropout_p in [0,1)");
   AttnParams p;
   p.qkv = (const bf16*)qkv; p.mask = (const int64_t*)mask; p.ctx = (bf16*)ctx; p.dctx = nullptr; p.lse = lse; p.dqkv = nullptr;
+  p.dbias_parts = nullptr;
   p.ld_qkv = ld_qkv; p.ld_ctx = ld_ctx; p.heads = heads; p.H = H; p.scale = 0.125f;
   p.seed = seed; p.stream = stream_id;
   p.thresh = dropout_p > 0.f ? (unsigned int)((double)dropout_p * 4294967296.0) : 0u;
@@ -342,25 +377,25 @@ extern "C" int mmsim_attn_fwd(const void* qkv, int ld_qkv, const long long* mask
   return mmsim_check_launch("attn_fwd");
 }
 
-extern "C" int mmsim_attn_bwd(const void* qkv, int ld_qkv, const long long* mask, const void* ctx, const void* dctx,
-                              int ld_ctx, const float* lse, void* dqkv, int B, int S, int heads, int H,
-                              float dropout_p, unsigned long long seed, unsigned int stream_id, void* stream) {
+static int attn_bwd_impl(const void* qkv, int ld_qkv, const long long* mask, const void* ctx, const void* dctx, int ld_ctx,
+                         const float* lse, void* dqkv, int B, int S, int heads, int H, float dropout_p, unsigned long long seed,
+                         unsigned int stream_id, float* dbias_parts, void* stream) {
   int rc = attn_check(B, S, heads, H, ld_qkv, ld_ctx, qkv);
   if (rc) return rc;
   MMSIM_REQUIRE(ctx && dctx && lse && dqkv, "attention bwd: null operand");
   AttnParams p;
   p.qkv = (const bf16*)qkv; p.mask = (const int64_t*)mask; p.ctx = (bf16*)ctx; p.dctx = (const bf16*)dctx;
-  p.lse = (float*)lse; p.dqkv = (bf16*)dqkv;
+  p.lse = (float*)lse; p.dqkv = (bf16*)dqkv; p.dbias_parts = dbias_parts;
   p.ld_qkv = ld_qkv; p.ld_ctx = ld_ctx; p.heads = heads; p.H = H; p.scale = 0.125f;
   p.seed = seed; p.stream = stream_id;
   p.thresh = dropout_p > 0.f ? (unsigned int)((double)dropout_p * 4294967296.0) : 0u;
   p.inv_keep = 1.0f / (1.0f - dropout_p);
   const int NT = S / 32;
-  const size_t lds = (size_t)S * (3 * ROW_PITCH + DST_PITCH) + 3 * S * 4;
+  const size_t lds = (size_t)S * (3 * ROW_PITCH + DST_PITCH) + 3 * S * 4 + 192 * 4;
   hipStream_t s = (hipStream_t)stream;
   static bool attr_done = false;
-  if (!attr_done) {   // S = 128 needs 65.5 KiB of dynamic LDS
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (3 * ROW_PITCH + DST_PITCH) + 3 * 128 * 4);
+  if (!attr_done) {   // S = 128 needs 66 KiB of dynamic LDS
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (3 * ROW_PITCH + DST_PITCH) + 3 * 128 * 4 + 192 * 4);
     attr_done = true;
   }
   dim3 grid(B * heads), block(64 * NT);
@@ -368,4 +403,25 @@ extern "C" int mmsim_attn_bwd(const void* qkv, int ld_qkv, const long long* mask
   else if (NT == 2) hipLaunchKernelGGL((attn_bwd_kernel<2>), grid, block, lds, s, p);
   else hipLaunchKernelGGL((attn_bwd_kernel<4>), grid, block, lds, s, p);
   return mmsim_check_launch("attn_bwd");
+}
+
+extern "C" int mmsim_attn_bwd(const void* qkv, int ld_qkv, const long long* mask, const void* ctx, const void* dctx,
+                              int ld_ctx, const float* lse, void* dqkv, int B, int S, int heads, int H,
+                              float dropout_p, unsigned long long seed, unsigned int stream_id, void* stream) {
+  return attn_bwd_impl(qkv, ld_qkv, mask, ctx, dctx, ld_ctx, lse, dqkv, B, S, heads, H, dropout_p, seed, stream_id, nullptr, stream);
+}
+
+void mmsim_launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s);   // conv.hip
+
+// attn_bwd that also accumulates dbias [3H] += column sums of dqkv (the q | k | v bias gradients) out of the kernel:
+// every (batch, head) workgroup leaves the sums of its 3 x 64 columns in a [B][3H] slab (scratch), reduced by one small launch.
+extern "C" int mmsim_attn_bwd_dbias(const void* qkv, int ld_qkv, const long long* mask, const void* ctx, const void* dctx,
+                                    int ld_ctx, const float* lse, void* dqkv, float* dbias, int B, int S, int heads, int H,
+                                    float dropout_p, unsigned long long seed, unsigned int stream_id, float* scratch,
+                                    unsigned long long scratch_floats, void* stream) {
+  MMSIM_REQUIRE(dbias && scratch && scratch_floats >= (unsigned long long)B * 3 * H, "attn_bwd_dbias: dbias and a scratch of B*3H floats required");
+  const int rc = attn_bwd_impl(qkv, ld_qkv, mask, ctx, dctx, ld_ctx, lse, dqkv, B, S, heads, H, dropout_p, seed, stream_id, scratch, stream);
+  if (rc) return rc;
+  mmsim_launch_reduce(scratch, B, 3 * H, dbias, 1, (hipStream_t)stream);
+  return mmsim_check_launch("attn_bwd_dbias");
 }

@@ -134,12 +134,21 @@ def attn_fwd(qkv, mask, ctx, lse, B, S, heads, H, dropout_p=0.0, seed=0, stream_
                  stream_id, _stream())
 
 
-def attn_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, heads, H, dropout_p=0.0, seed=0, stream_id=0):
+def attn_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, heads, H, dropout_p=0.0, seed=0, stream_id=0, dbias=None):
+    """dbias (fp32 [3H]): additionally dbias += dqkv.sum(0), out of the kernel (mmsim_attn_bwd_dbias)."""
     for t, n in ((qkv, "qkv"), (ctx, "ctx"), (dctx, "dctx"), (dqkv, "dqkv")):
         _chk(t, BF16, "attn_bwd." + n, 2)
     _chk(lse, F32, "attn_bwd.lse")
     if _ld(dqkv) != _ld(qkv) or _ld(dctx) != _ld(ctx):
         raise ValueError("attn_bwd: gradient buffers must share the leading dimensions of their primals")
+    if dbias is not None:
+        _chk(dbias, F32, "attn_bwd.dbias", 1)
+        if dbias.shape[0] != 3 * H:
+            raise ValueError("attn_bwd.dbias: length must be 3H")
+        scr = _scratch(dqkv.device, B * 3 * H)
+        lib.attn_bwd_dbias(_p(qkv), _ld(qkv), _p(mask), _p(ctx), _p(dctx), _ld(ctx), _p(lse), _p(dqkv), _p(dbias), B, S, heads, H,
+                           float(dropout_p), seed, stream_id, _p(scr), scr.numel(), _stream())
+        return
     lib.attn_bwd(_p(qkv), _ld(qkv), _p(mask), _p(ctx), _p(dctx), _ld(ctx), _p(lse), _p(dqkv), B, S, heads, H,
                  float(dropout_p), seed, stream_id, _stream())
 

@@ -138,6 +138,13 @@ def test_attention_fwd_bwd(S, masked):
     g = x.grad
     for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
         assert relerr(dqkv[:, sl], g[:, sl]) < 2e-2, name
+    # fused bias gradient: identical dqkv, dbias += column sums of the rounded values
+    dqkv2 = torch.empty_like(qkv)
+    dbias = torch.full((3 * H,), 0.5, device=DEV)
+    ops.attn_bwd(qkv, mask, ctx, dctx, lse, dqkv2, B, S, nh, H, dbias=dbias)
+    assert torch.equal(dqkv2, dqkv)
+    want = 0.5 + dqkv.float().double().sum(0)
+    assert (dbias.double() - want).abs().max() < 1e-4 * dqkv.float().abs().double().sum(0).max() + 1e-3
 
 
 def test_attention_dropout_statistics_and_consistency():
