@@ -40,13 +40,6 @@ int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, const void* 
                     void* C, int ldc, int c_is_f32, const float* bias, int epilogue, const void* aux_in,
                     void* aux_out, int ld_aux, float alpha, int split_k, int accumulate, void* stream);
 
-/* mmsim_gemm_bf16 with a bf16 result that also accumulates colsum[n] += sum_m C[m,n] (fp32, of the rounded values): the
- * bias gradient of the nn.Linear whose output gradient C is (modeling_bert.py:334-337 backward: d(intermediate.dense.bias)).
- * scratch: >= (M / 64) * N floats (used on the tile-aligned fast path; otherwise the column-sum kernel follows the GEMM). */
-int mmsim_gemm_bf16_colsum(int trans_a, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
-                           void* C, int ldc, const float* bias, int epilogue, const void* aux_in, void* aux_out, int ld_aux,
-                           float alpha, float* colsum, float* scratch, unsigned long long scratch_floats, void* stream);
-
 /* 1x1 conv whose input is the previous BatchNorm + SiLU (+ squeeze-excite gate) applied while the operand is
  * staged: x -> silu(xf_scale[c] x + xf_shift[c]) * xf_gate[pixel / xf_hw, c]  (gate may be NULL).
  *   xf_operand 1 (forward): C[P,Cout] = xf(A)[P,Cin] B[Cout,Cin]^T;  2 (wgrad): C[Cout,Cin] (+)= A[P,Cout]^T xf(B)[P,Cin].

@@ -24,8 +24,10 @@ from .flat import FlatBuffer
 from ._lib import MmsimError
 
 
-_FUSE = int(os.environ.get("MMSIM_FUSE_BIAS_GRADS", "1"))      # 0 separate column-sum passes, 1 both fused, 2 GEMM only, 3 attention only
-_FUSE_GEMM_BIAS, _FUSE_ATTN_BIAS = _FUSE in (1, 2), _FUSE in (1, 3)
+# q|k|v bias gradients out of attn_bwd (MMSIM_FUSE_BIAS_GRADS=0: separate column-sum pass).  The same fusion for the
+# intermediate.dense bias in the dX GEMM epilogue measured SLOWER on cfg4 (+1 ms/step: the epilogue is on the GEMM's critical
+# path, the column-sum pass it saves overlaps with the image tower's stream anyway) and was removed.
+_FUSE_ATTN_BIAS = os.environ.get("MMSIM_FUSE_BIAS_GRADS", "1") != "0"
 
 class BertConfig:
     """The subset of HF BertConfig the tower needs (defaults: hfl/chinese-roberta-wwm-ext)."""
@@ -302,9 +304,8 @@ class BertModel(nn.Module):
                        m.ph, m.seed, 4 * li + 2)
             ops.gemm(dT, ws.u[li], G(p + "output.dense.weight"), trans_a=True, b_kmajor=False, split_k=skI, accumulate=True)
             ops.gemm(dT, SV(p + "output.dense.weight"), ws.du, b_kmajor=False, epilogue=ops.EPI_MUL_GELU_GRAD,
-                     aux_in=ws.upre[li], colsum=G(p + "intermediate.dense.bias") if _FUSE_GEMM_BIAS else None)      # dX + bias gradient
-            if not _FUSE_GEMM_BIAS:
-                ops.colsum(ws.du, G(p + "intermediate.dense.bias"))
+                     aux_in=ws.upre[li])
+            ops.colsum(ws.du, G(p + "intermediate.dense.bias"))
             ops.gemm(ws.du, ws.h1[li], G(p + "intermediate.dense.weight"), trans_a=True, b_kmajor=False, split_k=skI,
                      accumulate=True)
             ops.gemm(ws.du, SV(p + "intermediate.dense.weight"), ws.dhb, b_kmajor=False)

@@ -223,7 +223,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 
 // C-ABI -- see include/mmsim_hip.h for the contract.
 bool gemm_fast_eligible(const GemmParams& p, int splits);
-int gemm_pp64_colsum_rows(const GemmParams& p, int trans_a, int splits);
 void gemm_fast_launch(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s);
 
 static bool force_generic() {
@@ -236,7 +235,7 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
                      int ldb, void* C, int ldc, int c_is_f32, const float* bias, int epilogue,
                      const void* aux_in, void* aux_out, int ld_aux, float alpha, int split_k,
                      int accumulate, int xf_operand, const float* xf_scale, const float* xf_shift, const float* xf_gate,
-                     int xf_hw, void* stream, float* stats = nullptr, float* colsum_slab = nullptr) {
+                     int xf_hw, void* stream, float* stats = nullptr) {
   MMSIM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: M, N, K must be positive");
   MMSIM_REQUIRE(A && B && C, "gemm: null operand");
   MMSIM_REQUIRE((lda % 8) == 0 && (ldb % 8) == 0, "gemm: lda/ldb must be multiples of 8 elements (16-byte rows)");
@@ -260,7 +259,7 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   p.c_f32 = c_is_f32; p.epi = epilogue; p.atomic = split_k > 1; p.accum = accumulate; p.alpha = alpha;
   p.xf_scale = xf_scale; p.xf_shift = xf_shift; p.xf_gate = xf_gate; p.xf_hw = xf_hw > 0 ? xf_hw : 1; p.xf_dhw = make_fastdiv(p.xf_hw);
   p.xf_C = (xf_operand == 1) ? K : N;
-  p.stats = stats; p.band = 1; p.colsum = colsum_slab;
+  p.stats = stats; p.band = 1;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MMSIM_GEMM_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
   int kps = (K + split_k - 1) / split_k;
@@ -339,32 +338,4 @@ extern "C" int mmsim_gemm_bf16_bnstats(int xf_operand, int M, int N, int K, cons
   if (rc) return rc;
   mmsim_launch_reduce(scratch, tiles_m, 2 * N, sums, 1, (hipStream_t)stream);
   return mmsim_check_launch("gemm_bnstats");
-}
-
-extern "C" int mmsim_colsum_bf16(const void* x, int ld, float* out, int M, int N, void* stream);      // rowwise.hip
-
-// nn.Linear backward through an activation: C = epilogue(op(A) op(B)) (bf16) AND colsum[n] += sum_m C[m, n], the bias gradient
-// of the layer that produced C's forward counterpart, taken from the rounded values the weight-gradient GEMM will read.
-// On the tile-aligned fast path the sums come out of the GEMM epilogue (per-tile slab + a small reduction); otherwise
-// the product is followed by the column-sum kernel.  scratch: >= (M / 64) * N floats.
-extern "C" int mmsim_gemm_bf16_colsum(int trans_a, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B,
-                                      int ldb, void* C, int ldc, const float* bias, int epilogue, const void* aux_in,
-                                      void* aux_out, int ld_aux, float alpha, float* colsum, float* scratch,
-                                      unsigned long long scratch_floats, void* stream) {
-  MMSIM_REQUIRE(colsum, "gemm_colsum: colsum required");
-  int rows = 0;
-  if (M > 0 && N > 0 && K > 0 && !force_generic()) {
-    GemmParams q;                       // only the fields the eligibility test reads
-    q.M = M; q.N = N; q.K = K; q.k_per_split = ((K + BK - 1) / BK) * BK; q.c_f32 = 0; q.epi = epilogue; q.ldc = ldc; q.ld_aux = ld_aux;
-    rows = gemm_pp64_colsum_rows(q, trans_a, 1);
-    if ((unsigned long long)rows * N > scratch_floats || !scratch) rows = 0;
-  }
-  const int rc = gemm_impl(trans_a, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, 0, bias, epilogue, aux_in, aux_out, ld_aux, alpha, 1,
-                           0, 0, nullptr, nullptr, nullptr, 1, stream, nullptr, rows ? scratch : nullptr);
-  if (rc) return rc;
-  if (rows) {
-    mmsim_launch_reduce(scratch, rows, N, colsum, 1, (hipStream_t)stream);
-    return mmsim_check_launch("gemm_colsum");
-  }
-  return mmsim_colsum_bf16(C, ldc, colsum, M, N, stream);
 }

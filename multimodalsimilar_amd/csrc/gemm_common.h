@@ -10,7 +10,6 @@ struct GemmParams {
   // optional operand transform (1x1 conv after BN + SiLU + squeeze-excite): x -> silu(scale[c] x + shift[c]) * gate[b, c]
   const float* xf_scale; const float* xf_shift; const float* xf_gate; int xf_hw, xf_C; FastDiv xf_dhw;
   int band;       // gemm_pp64_kernel: tile-rows per band of the tile walk
-  float* colsum;  // gemm_pp64_kernel, bf16 output: per-(M-tile, wave-row) column sums of the rounded output, slab [tiles_m * 256/WROWS][N] (NULL = off)
   float* stats;   // gemm_bf16_kernel, bf16 output, no split: per-M-tile column sum / sumsq slab [tiles_m][2][N] (NULL = off)
   int dbg;   // ablation switches for tools/bench_gemm.py (MMSIM_GEMM_DBG): 1 no DMA, 2 no LDS reads, 4 no MFMA; 0 in production
 };
@@ -25,7 +24,7 @@ enum { EPI_NONE = 0, EPI_GELU = 1, EPI_MUL_GELU_GRAD = 2, EPI_ADD = 3, EPI_TANH 
 #define EP_PITCH 68     // floats per staged row (64 + 4 pad: 16-byte aligned rows)
 template <int EPI, int CMODE, bool CHECK = false>     // CHECK: predicate rows / columns against M, N (ragged tiles)
 __device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][4], int row0, int col0, int lane, bool first_split,
-                                              float* tile, float* cs = nullptr) {      // cs[4]: running column sums (bf16 stores only)
+                                              float* tile) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -92,10 +91,6 @@ __device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][
     if (CMODE == 0) {
       bf4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
       *reinterpret_cast<bf4*>(reinterpret_cast<bf16*>(p.C) + m * p.ldc + n) = o;
-      if (cs) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cs[e] += bf2f(o[e]);
-      }
     } else {
       float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
       if (CMODE == 1) {
@@ -143,13 +138,13 @@ __device__ __forceinline__ void stats_epilogue(const GemmParams& p, f4 (&acc)[4]
 
 template <int CMODE, bool CHECK = false>
 __device__ __forceinline__ void fast_epilogue_epi(const GemmParams& p, f4 (&acc)[4][4], int row0, int col0, int lane, bool first_split,
-                                                  float* tile, float* cs = nullptr) {
+                                                  float* tile) {
   switch (p.epi) {
-    case EPI_GELU: fast_epilogue<EPI_GELU, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile, cs); break;
-    case EPI_MUL_GELU_GRAD: fast_epilogue<EPI_MUL_GELU_GRAD, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile, cs); break;
-    case EPI_ADD: fast_epilogue<EPI_ADD, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile, cs); break;
-    case EPI_TANH: fast_epilogue<EPI_TANH, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile, cs); break;
-    default: fast_epilogue<EPI_NONE, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile, cs); break;
+    case EPI_GELU: fast_epilogue<EPI_GELU, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile); break;
+    case EPI_MUL_GELU_GRAD: fast_epilogue<EPI_MUL_GELU_GRAD, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile); break;
+    case EPI_ADD: fast_epilogue<EPI_ADD, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile); break;
+    case EPI_TANH: fast_epilogue<EPI_TANH, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile); break;
+    default: fast_epilogue<EPI_NONE, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile); break;
   }
 }
 

@@ -306,26 +306,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     if (sacc == 12345.678f) reinterpret_cast<float*>(p.C)[0] = sacc;
     return;
   }
-  float cs[4] = {0.f, 0.f, 0.f, 0.f};
-  float* csp = (p.colsum && !p.c_f32) ? cs : nullptr;
 #pragma unroll
   for (int half = 0; half < MT / 4; ++half) {
     __syncthreads();
     f4 (&a4)[4][4] = *reinterpret_cast<f4 (*)[4][4]>(&acc[half * 4][0]);
     const int row0 = m0 + wm * WROWS + half * 64, col0 = n0 + wn * 64;
-    if (!p.c_f32) fast_epilogue_epi<0>(p, a4, row0, col0, lane, fs, stg, csp);
+    if (!p.c_f32) fast_epilogue_epi<0>(p, a4, row0, col0, lane, fs, stg);
     else if (p.atomic) fast_epilogue<EPI_NONE, 3>(p, a4, row0, col0, lane, fs, stg);
     else if (p.accum) fast_epilogue<EPI_NONE, 2>(p, a4, row0, col0, lane, fs, stg);
     else if (p.epi == EPI_TANH) fast_epilogue<EPI_TANH, 1>(p, a4, row0, col0, lane, fs, stg);
     else fast_epilogue<EPI_NONE, 1>(p, a4, row0, col0, lane, fs, stg);
-  }
-  if (csp) {                        // bias gradient fused into the producing GEMM: column sums of this wave's WROWS x 64 rounded outputs
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { cs[e] += __shfl_xor(cs[e], 16, 64); cs[e] += __shfl_xor(cs[e], 32, 64); }
-    if (lane < 16) {
-      constexpr int NWM = GBM / WROWS;
-      *reinterpret_cast<float4*>(p.colsum + (size_t)(tm * NWM + wm) * p.N + n0 + wn * 64 + lane * 4) = make_float4(cs[0], cs[1], cs[2], cs[3]);
-    }
   }
 }
 
@@ -376,14 +366,6 @@ static void launch_pipe(GemmParams p, int trans_a, int b_kmajor, int splits, hip
   else if (!trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_pp64_kernel<false, false, BN>), grid, block, lds, s, p);
   else if (trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_pp64_kernel<true, false, BN>), grid, block, lds, s, p);
   else hipLaunchKernelGGL((gemm_pp64_kernel<true, true, BN>), grid, block, lds, s, p);
-}
-
-// rows of the column-sum slab the pp64 kernel would write for this (non-transposed-A, unsplit) product; 0 = another kernel runs
-int gemm_pp64_colsum_rows(const GemmParams& p, int trans_a, int splits) {
-  if (trans_a || splits != 1 || tile_pref() == 1 || !gemm_fast_eligible(p, splits)) return 0;
-  if (pipe_eligible(p, splits, 256) && tile_pref() != 2) return (p.M / GBM) * 2;
-  if (pipe_eligible(p, splits, 128)) return (p.M / GBM) * 4;
-  return 0;
 }
 
 void gemm_fast_launch(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s) {

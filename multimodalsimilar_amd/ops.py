@@ -68,9 +68,8 @@ def alloc_2d(rows, cols, dtype, device, mult=8, zero=False):
 
 
 def gemm(a, b, c, *, trans_a=False, b_kmajor=True, bias=None, epilogue=EPI_NONE, aux_in=None, aux_out=None,
-         alpha=1.0, split_k=1, accumulate=False, colsum=None):
-    """c[M,N] = alpha * op(a) @ op(b) (+ bias) with fused epilogue; see mmsim_gemm_bf16.
-    colsum (fp32 [N], bf16 c only): additionally colsum += c.sum(0), out of the GEMM epilogue (mmsim_gemm_bf16_colsum)."""
+         alpha=1.0, split_k=1, accumulate=False):
+    """c[M,N] = alpha * op(a) @ op(b) (+ bias) with fused epilogue; see mmsim_gemm_bf16."""
     _chk(a, BF16, "gemm.a", 2); _chk(b, BF16, "gemm.b", 2)
     if c.dtype not in (BF16, F32):
         raise TypeError("gemm.c: bf16 or f32 output")
@@ -93,14 +92,6 @@ def gemm(a, b, c, *, trans_a=False, b_kmajor=True, bias=None, epilogue=EPI_NONE,
             if tuple(t.shape) != (M, N):
                 raise ValueError(f"{nm}: shape must equal the output shape")
             ld_aux = _ld(t)
-    if colsum is not None:
-        _chk(colsum, F32, "gemm.colsum", 1)
-        if c.dtype != BF16 or split_k != 1 or accumulate or colsum.shape[0] != N:
-            raise ValueError("gemm.colsum: needs a bf16 result, no split-K / accumulate, and an [N] fp32 vector")
-        scr = _scratch(c.device, max(1, (M + 63) // 64) * N)
-        lib.gemm_bf16_colsum(int(trans_a), int(b_kmajor), M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(c), _ld(c), _p(bias),
-                             epilogue, _p(aux_in), _p(aux_out), ld_aux, float(alpha), _p(colsum), _p(scr), scr.numel(), _stream())
-        return c
     lib.gemm_bf16(int(trans_a), int(b_kmajor), M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(c), _ld(c),
                   int(c.dtype == F32), _p(bias), epilogue, _p(aux_in), _p(aux_out), ld_aux, float(alpha), split_k,
                   int(accumulate), _stream())

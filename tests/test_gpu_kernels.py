@@ -269,23 +269,3 @@ def test_adamw_matches_golden(golden_dir):
             ref = torch.from_numpy(d[f"p{t + 1}_{j}"]).flatten().to(DEV)
             assert torch.allclose(p[offs[j]:offs[j] + sizes[j]], ref, rtol=2e-5, atol=1e-6)
     assert torch.equal(sh, p.bfloat16())
-
-
-@pytest.mark.parametrize("M,N,K,nn", [(4096, 2048, 128, True), (4096, 2048, 192, False), (16384, 384, 64, True),
-                                      (512, 256, 128, True), (300, 200, 96, True), (1024, 128, 192, False)])
-def test_gemm_with_fused_column_sums(M, N, K, nn):
-    """mmsim_gemm_bf16_colsum: the bf16 product equals the plain GEMM and colsum += C.sum(0) of the ROUNDED values, on the
-    tile-aligned fast path (epilogue slab) and on the fallback (product + column-sum kernel) alike."""
-    from multimodalsimilar_amd import ops
-    torch.manual_seed(M + N)
-    a = (torch.randn(M, K, device=DEV) * 0.5).bfloat16()
-    b = (torch.randn(K, N, device=DEV) * 0.5).bfloat16() if nn else (torch.randn(N, K, device=DEV) * 0.5).bfloat16()
-    aux = torch.randn(M, N, device=DEV).bfloat16()
-    c0 = ops.alloc_2d(M, N, torch.bfloat16, DEV)
-    c1 = ops.alloc_2d(M, N, torch.bfloat16, DEV)
-    ops.gemm(a, b, c0, b_kmajor=not nn, epilogue=ops.EPI_MUL_GELU_GRAD, aux_in=aux)
-    cs = torch.full((N,), 3.0, device=DEV)
-    ops.gemm(a, b, c1, b_kmajor=not nn, epilogue=ops.EPI_MUL_GELU_GRAD, aux_in=aux, colsum=cs)
-    assert torch.equal(c0[:, :N], c1[:, :N])
-    want = 3.0 + c1[:, :N].float().double().sum(0)
-    assert (cs.double() - want).abs().max() < 1e-4 * c1[:, :N].float().abs().double().sum(0).max() + 1e-3
