@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--ragged-masks", action="store_true", help="per-row sequence lengths ~ U{8..S} (SURVEY 8d realism run; not the headline)")
     ap.add_argument("--literal-loss", action="store_true", help="materialised logits + nn.CrossEntropyLoss instead of the fused head")
     args = ap.parse_args()
 
@@ -187,7 +188,7 @@ def main():
         cfg["batch"] = args.batch
     model = train.build_model(cfg, device, seed=0, dropout=not args.no_dropout)
     step = train.TrainStep(model, cfg["kind"], num_training_steps=10 ** 6, fused_loss=not args.literal_loss)
-    batch = train.synthetic_batch(cfg, device, seed=1234 + rank)
+    batch = train.synthetic_batch(cfg, device, seed=1234 + rank, ragged_masks=args.ragged_masks)
     timer = GemmTimer(ops)
     timer.install()
 
@@ -246,7 +247,7 @@ def main():
                                                         "nlp": "text tower + ArcFace", "cv": "image tower + ArcFace"}[cfg["kind"]],
                        "per_gpu_batch": cfg["batch"], "global_batch": world * cfg["batch"], "seq_len": cfg.get("seq_len"),
                        "image": cfg.get("res"), "classes": cfg["classes"], "parallelism": f"dp{world}",
-                       "dropout": not args.no_dropout, "loss_path": "literal" if args.literal_loss else "fused",
+                       "dropout": not args.no_dropout, "attention_mask": "ragged U{8..S}" if args.ragged_masks else "all ones", "loss_path": "literal" if args.literal_loss else "fused",
                        "algorithmic_gflop_per_pair": fpp / 1e9,
                        "step_mfma_frac": (fpp * cfg["batch"] / (ms * 1e-3) / 1e12) / MFMA_BF16_PEAK_TFLOPS,
                        "final_loss": lossv},

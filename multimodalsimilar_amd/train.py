@@ -69,9 +69,10 @@ def build_model(cfg, device, seed=0, dropout=True):
     return MultimodalClassifier(device, cv, nlp, emb_size=emb, num_labels=c.classes)
 
 
-def synthetic_batch(cfg, device, seed=1234, batch=None, vocab=None):
+def synthetic_batch(cfg, device, seed=1234, batch=None, vocab=None, ragged_masks=False):
     """images ~ N(0,1) fp32 NCHW, ids uniform with [CLS]=101 at position 0, token types 0,
-    all-ones attention mask, labels uniform."""
+    all-ones attention mask (the roofline run) or, with ragged_masks, per-row lengths ~ U{8..S} zero-padded to S as the
+    reference pads to max_length (multimodal_dataset.py:44-48; the realism run), labels uniform."""
     c = SimpleNamespace(**cfg)
     B = batch or c.batch
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -84,7 +85,11 @@ def synthetic_batch(cfg, device, seed=1234, batch=None, vocab=None):
         ids[:, 0] = 101
         out["input_ids"] = ids.to(device)
         out["token_type_ids"] = torch.zeros(B, c.seq_len, dtype=torch.long, device=device)
-        out["attention_mask"] = torch.ones(B, c.seq_len, dtype=torch.long, device=device)
+        if ragged_masks:
+            lens = torch.randint(min(8, c.seq_len), c.seq_len + 1, (B,), generator=g)
+            out["attention_mask"] = (torch.arange(c.seq_len).unsqueeze(0) < lens.unsqueeze(1)).long().to(device)
+        else:
+            out["attention_mask"] = torch.ones(B, c.seq_len, dtype=torch.long, device=device)
     out["labels"] = torch.randint(0, c.classes, (B,), generator=g).to(device)
     return out
 
