@@ -62,12 +62,10 @@ def _pmc_traffic(config):
     cannot be read inside this process, so the figure is only reported for the workload it was measured on (cfg4 / cfg3)."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_gemm_pp64.json")
     if config not in ("cfg4", "cfg3") or not os.path.exists(path):
-        return None
+        return None, None
     with open(path) as f:
         d = json.load(f)
-    return {"hbm_bytes_per_launch": d["mean_hbm_bytes_per_launch"],
-            "algorithmic_bytes_per_launch": sum(r["algorithmic_bytes"] for r in d["per_shape"]) / len(d["per_shape"]),
-            "source": "profiles/r01_pmc_gemm_pp64.json"}
+    return d["mean_hbm_bytes_per_launch"], sum(r["algorithmic_bytes"] for r in d["per_shape"]) / len(d["per_shape"])
 
 
 class GemmTimer:
@@ -254,7 +252,9 @@ def main():
             "roofline": None if g is None else {
                 "bound": "mfma", "kernel": "gemm_pp64_kernel<false,true,256> (Y = X W^T: 256x256 tiles, 64-deep LDS-DMA slices, ping-pong wave groups, bf16 MFMA 16x16x32, fp32 accumulate)",
                 "achieved": g["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": _pmc_traffic(args.config), "launches": g["launches"], "avg_launch_us": g["avg_us"],
+                "traffic": _pmc_traffic(args.config)[0], "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_gemm_pp64.json)",
+                "algorithmic_bytes_per_launch": _pmc_traffic(args.config)[1],
+                "launches": g["launches"], "avg_launch_us": g["avg_us"],
                 "concurrent_with": "image-tower kernels on a second stream" if g_excl else None,
                 "achieved_exclusive": g_excl["tflops"] if g_excl else None,
                 "frac_exclusive": g_excl["tflops"] / MFMA_BF16_PEAK_TFLOPS if g_excl else None},
