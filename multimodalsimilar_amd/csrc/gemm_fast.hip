@@ -177,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p) {
 // Ping-pong kernel with 64-deep K-slices (the production path for tile-aligned products).
 // 256 x BN output tiles, 8 waves (BN = 256: 2 x 4 waves of 128 x 64; BN = 128: 4 x 2 waves of 64 x 64), operands by
 // LDS-DMA.  The eight waves are two groups of four (waves w and w+4 share a SIMD) running in ANTI-PHASE: group 1 executes
-// one extra barrier before its loop, so while one wave of a SIMD issues its 32 MFMAs back to back (raised priority) its
+// one extra barrier before its loop, so while one wave of a SIMD issues its 32 MFMAs back to back its
 // partner issues LDS reads and DMA descriptors.  With a single barrier per step both waves of a SIMD reach their ~500-cycle
 // load section together and the matrix pipe idles through it (measured with the 32-deep predecessors of this kernel:
 // single barrier 930, anti-phase 978, anti-phase + 64-deep slices 1056 TFLOP/s on the text shapes).
@@ -261,11 +261,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
   __builtin_amdgcn_s_barrier();                                                                          \
   __builtin_amdgcn_sched_barrier(0);                                                                     \
   if (!(p.dbg & 4)) {                                                                                    \
-    __builtin_amdgcn_s_setprio(1);                                                                       \
+    /* no s_setprio around the MFMAs: measured 1 % slower with it on this schedule (the partner wave is in its load phase) */ \
     _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                       \
       _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);          \
-    __builtin_amdgcn_s_setprio(0);                                                                       \
   }                                                                                                      \
   __builtin_amdgcn_sched_barrier(0);
   for (int u = 0; u < ns; ++u) {
