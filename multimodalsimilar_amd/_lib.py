@@ -9,7 +9,7 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "mmsim_hip.h")
-LIBPATH = os.path.join(HERE, "libmmsim_hip.so")
+LIBPATH = os.environ.get("MMSIM_LIB") or os.path.join(HERE, "libmmsim_hip.so")      # MMSIM_LIB: A/B a second build of the library
 
 _SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "unsigned long long": ctypes.c_uint64,
             "unsigned int": ctypes.c_uint32, "long long": ctypes.c_int64}
