@@ -15,16 +15,19 @@ from multimodalsimilar_amd.bert import as_native
 
 
 class NlpClassifierMultilabel(nn.Module):
+    MARGINS = (0.4, 0.2, 0.1)       # first category, second category, tag (reference :15-17)
+
     def __init__(self, pretrained_model, firstcate_num_labels, secondcate_num_labels, tag_num_labels, emb_size=128, dropout=None):
         super().__init__()
-        self.ptm = as_native(pretrained_model)
-        self.dropout = nn.Dropout(p=dropout if dropout is not None else 0.1)     # never applied (reference :10)
+        tower = as_native(pretrained_model)
+        self.ptm = tower
+        self.dropout = nn.Dropout(p=0.1 if dropout is None else dropout)         # created, never applied (reference :10)
         self.emb_size = emb_size
-        self.emb_layer = TransformerEmb(self.ptm)                                # reference :14 (no emb_size: default 128)
-        hidden = self.ptm.config.hidden_size
-        self.firstcate_classifier = ArcMarginProduct(hidden, firstcate_num_labels, m=0.4)     # :15
-        self.secondcate_classifier = ArcMarginProduct(hidden, secondcate_num_labels, m=0.2)   # :16
-        self.tag_classifier = ArcMarginProduct(hidden, tag_num_labels, m=0.1)                 # :17
+        self.emb_layer = TransformerEmb(tower)                                   # the reference passes no emb_size here (:14)
+        width = tower.config.hidden_size
+        sizes = (firstcate_num_labels, secondcate_num_labels, tag_num_labels)
+        first, second, tag = (ArcMarginProduct(width, n, m=m) for n, m in zip(sizes, self.MARGINS))
+        self.firstcate_classifier, self.secondcate_classifier, self.tag_classifier = first, second, tag
 
     def _heads(self):
         return self.firstcate_classifier, self.secondcate_classifier, self.tag_classifier
