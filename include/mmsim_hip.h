@@ -206,6 +206,17 @@ int mmsim_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_sh
                      float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                      void* stream);
 
+/* ---- exhaustive inner-product top-k search (nlp_infer.py:139-152, daodian_infer.py:225-230, 295-302:
+ * faiss.normalize_L2 + IndexFlat(METRIC_INNER_PRODUCT).add / .search) ------------------------------------------------
+ * mmsim_split_bf16_cat: x fp32 [R, D] (* scale) -> bf16 [R, 3D]: [hi | lo | hi] for queries (db_side 0), [hi | hi | lo] for the
+ * database (db_side 1), hi = bf16(x), lo = bf16(x - hi): one bf16 GEMM over K = 3D (mmsim_gemm_bf16, fp32 result) then
+ * gives the fp32 inner products to ~2^-16 relative.
+ * mmsim_topk_merge: folds scores [nq, n] (columns = database rows col_offset ..) into the running lists best_val / best_idx
+ * [nq, k] (descending score, equal scores by ascending index; first != 0: the lists are empty on entry).  k <= 64. */
+int mmsim_split_bf16_cat(const float* x, int ldx, void* out, int ldo, int R, int D, int db_side, float scale, void* stream);
+int mmsim_topk_merge(const float* scores, int ld, int nq, int n, long long col_offset, int k, float* best_val,
+                     long long* best_idx, int first, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

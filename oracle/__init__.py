@@ -17,6 +17,11 @@ Pinning status (see DESIGN.md "Oracle"):
                        which is neither vendored in the reference nor installed here, and the
                        reference's tests hold no vectors for it.  effnet_ref restates timm's
                        published ``efficientnet_b0/b4`` architecture.
+  * search_ref       - PARITY UNPINNED: the similarity search after the model (nlp_infer.py:139-152) is ``faiss``
+                       (no pinned version, not installed, no vectors in the reference's tests); restates
+                       IndexFlat / METRIC_INNER_PRODUCT semantics, equal scores by ascending index.
+  * multilabel       - pinned: bert_ref + three arcface_ref heads against the reference's
+                       ``NlpClassifierMultilabel`` run here (tests/golden/nlp_multilabel.npz).
   * optim_ref        - pinned against torch.optim.AdamW + transformers.get_scheduler("linear"),
                        the exact objects the reference's train script constructs.
 """

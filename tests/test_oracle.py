@@ -164,3 +164,19 @@ def test_effnet_oracle_shapes_and_published_counts():
     a4 = effnet_ref.arch("efficientnet_b4")
     assert a4["stem"] == 48 and a4["head"] == 1792 and len(a4["blocks"]) == 32
     assert [b["cout"] for b in a4["blocks"]][:7] == [24, 24, 32, 32, 32, 32, 56]
+
+
+def test_search_oracle_properties():
+    """oracle/search_ref.py (faiss IndexFlat inner product, restated; unpinned): rows normalised, scores descending, self first,
+    ties by ascending index, -1 / -inf padding when fewer than k vectors are stored."""
+    import numpy as np
+    from oracle import search_ref
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((40, 16)).astype(np.float32)
+    x[11] = x[3]
+    D, I = search_ref.search_inner_product(x, x, 5)
+    assert np.all(np.diff(D, axis=1) <= 1e-7) and np.allclose(D[:, 0], 1.0, atol=1e-5)
+    assert list(I[3, :2]) == [3, 11] and list(I[11, :2]) == [3, 11]
+    D2, I2 = search_ref.search_inner_product(x[:2], x[:3], 5)
+    assert np.all(I2[:, 3:] == -1) and np.all(np.isinf(D2[:, 3:]))
+    assert np.allclose(np.linalg.norm(search_ref.normalize_l2(x), axis=1), 1.0, atol=1e-6)
