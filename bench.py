@@ -11,7 +11,11 @@ all-reduce (N > 1) + both fused AdamW updates + LR schedules: nothing is skipped
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline     - the dominant kernel (the bf16 MFMA GEMM gemm_pp64_kernel<false,true,256>, Y = X W^T): algorithmic
                  FLOPs (2 M N K per launch) / its mean launch duration measured with HIP events on the launch stream
-                 over the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak (MI355X_MICROARCH.md);
+                 over the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak (MI355X_MICROARCH.md).  The towers
+                 run on two HIP streams, so inside the timed region these launches time-share the chip with image-tower
+                 kernels; `achieved_exclusive` is the same measurement over two untimed steps with one stream, taken right
+                 after the timed region; `traffic` is the fabric-side bytes per launch from separate rocprofv3 --pmc passes
+                 (profiles/r01_pmc_gemm_pp64.json);
   cpu_baseline - the oracle's CPU restatement of the same step (oracle/step_ref.py, kind "port") on the host cores,
                  on a bounded sample (same model, B_cpu pairs per step).
 """
