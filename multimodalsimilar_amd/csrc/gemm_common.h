@@ -73,11 +73,11 @@ __device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][
     float v[4] = {a[0] * p.alpha + bias.x, a[1] * p.alpha + bias.y, a[2] * p.alpha + bias.z, a[3] * p.alpha + bias.w};
     if (EPI == EPI_GELU) {
       bf4 pre = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-      *reinterpret_cast<bf4*>(p.aux_out + m * p.ld_aux + n) = pre;
+      __builtin_nontemporal_store(pre, reinterpret_cast<bf4*>(p.aux_out + m * p.ld_aux + n));      // only read again in backward
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = gelu_f(bf2f(pre[e]));
     } else if (EPI == EPI_MUL_GELU_GRAD) {
-      const bf4 x = *reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n);
+      const bf4 x = __builtin_nontemporal_load(reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n));      // read once
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(bf2f(x[e]));
     } else if (EPI == EPI_ADD) {
@@ -90,7 +90,7 @@ __device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][
     }
     if (CMODE == 0) {
       bf4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-      *reinterpret_cast<bf4*>(reinterpret_cast<bf16*>(p.C) + m * p.ldc + n) = o;
+      __builtin_nontemporal_store(o, reinterpret_cast<bf4*>(reinterpret_cast<bf16*>(p.C) + m * p.ldc + n));
     } else {
       float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
       if (CMODE == 1) {

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16* t, const bf
       a = make_float4(a.x + r.x, a.y + r.y, a.z + r.z, a.w + r.w);
       // statistics are taken on the bf16-rounded sum that backward will read back
       bf4 rb = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w)};
-      *reinterpret_cast<bf4*>(y + (size_t)row * H + col) = rb;
+      __builtin_nontemporal_store(rb, reinterpret_cast<bf4*>(y + (size_t)row * H + col));      // read again only in backward
       v[c] = make_float4(bf2f(rb[0]), bf2f(rb[1]), bf2f(rb[2]), bf2f(rb[3]));
       nc = c + 1;
     }
