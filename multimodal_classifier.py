@@ -114,4 +114,6 @@ class MultimodalClassifier(nn.Module):
         if s is None or s.device != torch.device(device):
             s = torch.cuda.Stream(device=device, priority=int(os.environ.get("MMSIM_SIDE_PRIORITY", "0")))
             object.__setattr__(self, "_side", s)          # not a module attribute: never pickled / moved
+            from multimodalsimilar_amd import ops
+            ops.register_side_stream(s)                   # FusedAdamW.step / GradientExchange.finish wait for it
         return s

@@ -65,6 +65,9 @@ class GradientExchange:
     def finish(self):
         """After loss.backward(): send whatever was not reported through hooks, then wait for everything."""
         if self.world > 1:
+            if any(f.grad is not None and f.grad.is_cuda for f in self.flats):
+                from . import ops
+                ops.join_side_streams()     # ranges launched below may have been written on a tower's side stream
             for f in self.flats:
                 cur = self._pending.get(id(f))
                 if cur is not None:

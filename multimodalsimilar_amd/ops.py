@@ -21,6 +21,28 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Side streams a model launches tower work on (multimodal_classifier.py: the image tower).  Whatever consumes the flat
+# gradient buffers after backward -- the optimiser kernels, the gradient exchange -- first makes ITS stream wait for them:
+# the towers write flat.grad with their own kernels (no AccumulateGrad node), so the ordering is stated here explicitly
+# instead of being left to autograd's leaf-stream bookkeeping.
+_side_streams = []
+
+
+def register_side_stream(s):
+    if all(s is not t for t in _side_streams):
+        _side_streams.append(s)
+
+
+def join_side_streams():
+    """The current stream waits for everything enqueued so far on the registered side streams of its device."""
+    if not _side_streams:
+        return
+    cur = torch.cuda.current_stream()
+    for s in _side_streams:
+        if s.device == cur.device and s != cur:
+            cur.wait_stream(s)
+
+
 def _chk(t, dtype, name, dims=None):
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a tensor, got {type(t).__name__}")

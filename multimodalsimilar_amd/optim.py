@@ -62,6 +62,8 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         g = self.param_groups[0]
         self._t += 1
+        if self.flats[0].master.is_cuda:
+            ops.join_side_streams()      # gradients written by a tower on its own stream (multimodal_classifier.py)
         for f in self.flats:
             if f.grad is None:
                 continue          # never produced a gradient: skipped like torch skips grad-is-None params
