@@ -217,6 +217,18 @@ int mmsim_split_bf16_cat(const float* x, int ldx, void* out, int ldo, int R, int
 int mmsim_topk_merge(const float* scores, int ld, int nq, int n, long long col_offset, int k, float* best_val,
                      long long* best_idx, int first, void* stream);
 
+/* ---- image input stage (multimodal_infer.py:86-91, cv_classifier_train.py:39-40: timm create_transform =
+ * torchvision Resize(bicubic, PIL) -> CenterCrop -> ToTensor -> Normalize) -------------------------------------------
+ * One image: img [H][W][3] uint8 (row pitch in bytes) -> out [3][S][S] fp32.  bx/by [out][2] = (first input index, tap
+ * count) and kx/ky [out][ks] = Pillow's 22-bit fixed-point bicubic kernels for the whole resized axis (built on the host,
+ * multimodalsimilar_amd/preprocess.py); (left, top, S) is the crop window in the resized image; pass 1 covers input rows
+ * [row0, row0 + nrows) into tmp (>= nrows * S * 4 bytes).  Bit-exact with Pillow's 8-bit two-pass resampling; ToTensor /
+ * Normalize in fp32 with correctly rounded divisions. */
+int mmsim_preprocess_image(const void* img, int H, int W, int pitch, const int* bx, const int* kx, int ksx, int out_w,
+                           const int* by, const int* ky, int ksy, int out_h, int left, int top, int S, int row0, int nrows,
+                           void* tmp, unsigned long long tmp_bytes, float* out, float mean0, float mean1, float mean2,
+                           float std0, float std1, float std2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,12 @@
 
 #define ROW_PITCH 144   // bytes, row reads (ds_read_b128) conflict-free
 #define TRV_PITCH 192   // bytes, forward V image: transposed reads conflict-free
+#ifndef ATTN_FWD_WAVES
+#define ATTN_FWD_WAVES 3      // 155 VGPRs, no spills: three 43.5 KiB workgroups per CU instead of two
+#endif
+#ifndef ATTN_BWD_WAVES
+#define ATTN_BWD_WAVES 2
+#endif
 #define DST_PITCH 80    // bytes, dS^T image rows of 32 bf16
 
 struct AttnParams {
@@ -23,33 +29,6 @@ struct AttnParams {
   unsigned long long seed; unsigned int stream, thresh; float inv_keep;
 };
 
-typedef s4 __attribute__((address_space(3))) * lds_s4_ptr;
-
-__device__ __forceinline__ bf8 tr_pair(const char* base, int off_lo, int row_step_bytes8) {
-  s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(base + off_lo));
-  s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(base + off_lo + row_step_bytes8));
-  s8 r;
-  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-  return __builtin_bit_cast(bf8, r);
-}
-
-// A-operand fragment of X^T for a 32x32x16 MFMA whose B operand is an accumulator tile:
-// image rows = reduction index (row0 + 16*s2 + ...), image cols = output rows (col0 + lane&31).
-__device__ __forceinline__ bf8 tr_frag32(const char* img, int pitch, int row0, int s2, int col0, int lane) {
-  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, hh = g >> 1;
-  const int row = row0 + 16 * s2 + 4 * hh + q;
-  const int col = col0 + 16 * (g & 1) + 4 * p;
-  return tr_pair(img, row * pitch + col * 2, 8 * pitch);
-}
-// operand fragment for a 16x16x32 MFMA: image rows = reduction index (row0 + 8*(lane>>4) + ...), cols col0 + lane&15
-__device__ __forceinline__ bf8 tr_frag16(const char* img, int pitch, int row0, int col0, int lane) {
-  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-  const int row = row0 + 8 * g + q;
-  const int col = col0 + 4 * p;
-  return tr_pair(img, row * pitch + col * 2, 4 * pitch);
-}
-
 __device__ __forceinline__ bf8 cvt8(const f16v& a, int s2, float mul) {
   bf8 r;
 #pragma unroll
@@ -58,7 +37,7 @@ __device__ __forceinline__ bf8 cvt8(const f16v& a, int s2, float mul) {
 }
 
 template <int NT>
-__global__ __launch_bounds__(64 * NT) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_FWD_WAVES))) void attn_fwd_kernel(AttnParams p) {
   constexpr int S = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;                       // [S][ROW_PITCH]
@@ -167,62 +146,79 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_kernel(AttnParams p) {
     }
 }
 
+// Backward.  LDS holds the K image, ONE 32-row tile of Q and dO at a time (double-buffered: the next tile's q | dO | O rows
+// are requested from HBM into registers before the current tile's products and parked in the other buffer after them, so
+// the loads ride under the MFMA / exp work instead of in front of it), and the dS^T image: 48 KiB at S = 128.
+// delta[q] = sum_d dO[q][d] O[q][d] comes out of the staging step (the thread that parks a 16-byte dO chunk also holds the
+// matching O chunk: an 8-lane shuffle sum per row), so dO and O are read from HBM exactly once.
 template <int NT>
-__global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BWD_WAVES))) void attn_bwd_kernel(AttnParams p) {
   constexpr int S = 32 * NT;
   constexpr int TPW = 8 / NT;   // dQ 16x16 tiles per wave per query tile
+  constexpr int NTHR = 64 * NT;
+  constexpr int CPT = 256 / NTHR;           // 16-byte chunks of a 32-row tile per thread and operand
+  constexpr int TILE = 32 * ROW_PITCH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Qs = smem;                          // [S][ROW_PITCH]
-  char* Os = smem + S * ROW_PITCH;          // dO
-  char* Ks = smem + 2 * S * ROW_PITCH;      // K
-  char* Ds = smem + 3 * S * ROW_PITCH;      // dS^T [S keys][DST_PITCH] for the current query tile
-  float* fl = reinterpret_cast<float*>(smem + 3 * S * ROW_PITCH + S * DST_PITCH);
-  float* lse = fl; float* dl = fl + S; float* mb = fl + 2 * S;
-  float* cb = fl + 3 * S;                   // [192] column sums of this (b, h)'s dq | dk | dv (bias gradient of the QKV projection)
+  char* Qt = smem;                          // [2][32][ROW_PITCH]
+  char* Ot = smem + 2 * TILE;               // dO, [2][32][ROW_PITCH]
+  char* Ks = smem + 4 * TILE;               // K [S][ROW_PITCH]
+  char* Ds = Ks + S * ROW_PITCH;            // dS^T [S keys][DST_PITCH] for the current query tile
+  float* fl = reinterpret_cast<float*>(Ds + S * DST_PITCH);
+  float* lse = fl; float* dlt = fl + S; float* mb = fl + S + 64;     // dlt: [2][32] delta of the staged tiles
+  float* cb = fl + 2 * S + 64;              // [192] column sums of this (b, h)'s dq | dk | dv (bias gradient of the QKV projection)
   float cq[TPW][4];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) cq[t][0] = cq[t][1] = cq[t][2] = cq[t][3] = 0.f;
   if (p.dbias_parts)
-    for (int i = threadIdx.x; i < 192; i += 64 * NT) cb[i] = 0.f;       // ordered before the adds by the barriers of the loop
+    for (int i = threadIdx.x; i < 192; i += NTHR) cb[i] = 0.f;       // ordered before the adds by the barriers of the loop
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5;
   const int bh = blockIdx.x, b = bh / p.heads, h = bh % p.heads;
   const bf16* base = p.qkv + (size_t)b * S * p.ld_qkv + h * 64;
   const bf16* dob = p.dctx + (size_t)b * S * p.ld_ctx + h * 64;
   const bf16* ob = p.ctx + (size_t)b * S * p.ld_ctx + h * 64;
 
-  {   // 4 trips x 3 operands: all 12 loads requested before the first LDS store
-    uint4 qv[4], kv[4], ov[4];
+  uint4 tq[CPT], to[CPT], tc[CPT];          // the tile in flight: q, dO, O chunks
+  auto issue = [&](int qt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + i * 64 * NT, row = c >> 3, ch = c & 7;
-      qv[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * p.ld_qkv + ch * 8);
-      kv[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * p.ld_qkv + p.H + ch * 8);
-      ov[i] = *reinterpret_cast<const uint4*>(dob + (size_t)row * p.ld_ctx + ch * 8);
+    for (int i = 0; i < CPT; ++i) {
+      const int c = tid + i * NTHR, row = 32 * qt + (c >> 3), ch = c & 7;
+      tq[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * p.ld_qkv + ch * 8);
+      to[i] = *reinterpret_cast<const uint4*>(dob + (size_t)row * p.ld_ctx + ch * 8);
+      tc[i] = *reinterpret_cast<const uint4*>(ob + (size_t)row * p.ld_ctx + ch * 8);
     }
+  };
+  auto park = [&](int bf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + i * 64 * NT, row = c >> 3, ch = c & 7;
-      *reinterpret_cast<uint4*>(Qs + row * ROW_PITCH + ch * 16) = qv[i];
-      *reinterpret_cast<uint4*>(Ks + row * ROW_PITCH + ch * 16) = kv[i];
-      *reinterpret_cast<uint4*>(Os + row * ROW_PITCH + ch * 16) = ov[i];
-    }
-  }
-  for (int i = tid; i < S; i += 64 * NT) {
-    mb[i] = (p.mask && p.mask[(size_t)b * S + i] == 0) ? -1e30f : 0.f;
-    lse[i] = p.lse[(size_t)bh * S + i];
-  }
-  {  // delta[q] = sum_d dO[q][d] * O[q][d]; lane&31 = row of this wave's 32 rows, hh = half of d
-    const int row = 32 * w + (lane & 31);
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const bf8 a = *reinterpret_cast<const bf8*>(dob + (size_t)row * p.ld_ctx + 32 * hh + 8 * c);
-      const bf8 o = *reinterpret_cast<const bf8*>(ob + (size_t)row * p.ld_ctx + 32 * hh + 8 * c);
+    for (int i = 0; i < CPT; ++i) {
+      const int c = tid + i * NTHR, row = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(Qt + bf * TILE + row * ROW_PITCH + ch * 16) = tq[i];
+      *reinterpret_cast<uint4*>(Ot + bf * TILE + row * ROW_PITCH + ch * 16) = to[i];
+      const bf8 a = __builtin_bit_cast(bf8, to[i]), o = __builtin_bit_cast(bf8, tc[i]);
+      float acc = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc += bf2f(a[j]) * bf2f(o[j]);
+      acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);   // the 8 chunks of a row
+      if (ch == 0) dlt[bf * 32 + row] = acc;
     }
-    acc += __shfl_xor(acc, 32, 64);
-    if (hh == 0) dl[row] = acc;
+  };
+
+  {   // K image (4 chunks per thread) + tile 0: every load requested before the first LDS store
+    uint4 kv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * NTHR, row = c >> 3, ch = c & 7;
+      kv[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * p.ld_qkv + p.H + ch * 8);
+    }
+    issue(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * NTHR, row = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(Ks + row * ROW_PITCH + ch * 16) = kv[i];
+    }
+  }
+  for (int i = tid; i < S; i += NTHR) {
+    mb[i] = (p.mask && p.mask[(size_t)b * S + i] == 0) ? -1e30f : 0.f;
+    lse[i] = p.lse[(size_t)bh * S + i];
   }
   // loop-invariant B operands: K^T and V^T columns for this wave's 32 keys (lane = key)
   const int key = 32 * w + (lane & 31);
@@ -232,6 +228,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
     kreg[kk] = *reinterpret_cast<const bf8*>(base + (size_t)key * p.ld_qkv + p.H + 16 * kk + 8 * hh);
     vreg[kk] = *reinterpret_cast<const bf8*>(base + (size_t)key * p.ld_qkv + 2 * p.H + 16 * kk + 8 * hh);
   }
+  park(0);
   __syncthreads();
   const float mbk = mb[key];
   const uint32_t dkey = drop_key(p.seed, p.stream);
@@ -242,13 +239,19 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dV[dt][i] = 0.f; dK[dt][i] = 0.f; }
 
+#pragma unroll 1
   for (int qt = 0; qt < NT; ++qt) {
+    const int cur = qt & 1;
+    const char* Qs = Qt + cur * TILE;       // rows of this query tile
+    const char* Os = Ot + cur * TILE;
+    const float* dl = dlt + cur * 32;
+    if (qt + 1 < NT) issue(qt + 1);
     f16v X, dP;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { X[i] = 0.f; dP[i] = 0.f; }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const int off = (32 * qt + (lane & 31)) * ROW_PITCH + (16 * kk + 8 * hh) * 2;
+      const int off = (lane & 31) * ROW_PITCH + (16 * kk + 8 * hh) * 2;
       const bf8 qa = *reinterpret_cast<const bf8*>(Qs + off);
       const bf8 oa = *reinterpret_cast<const bf8*>(Os + off);
       X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kreg[kk], X, 0, 0, 0);
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
     // X[r] -> P (dropped, for dV) ; dP[r] -> dS
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int q = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh, q = 32 * qt + ql;
       const float pr = __expf(X[r] * p.scale + mbk - lse[q]);
       float ks = 1.0f;
       if (p.thresh) {
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
         ks = drop_keep16(drop_bits(dkey, idx >> 1), key & 1, p.thresh) ? p.inv_keep : 0.f;
       }
       X[r] = pr * ks;
-      dP[r] = pr * (dP[r] * ks - dl[q]);
+      dP[r] = pr * (dP[r] * ks - dl[ql]);
     }
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -273,8 +276,8 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf8 pb = cvt8(X, s2, 1.0f);
         const bf8 sb = cvt8(dP, s2, 1.0f);
-        const bf8 of = tr_frag32(Os, ROW_PITCH, 32 * qt, s2, 32 * dt, lane);
-        const bf8 qf = tr_frag32(Qs, ROW_PITCH, 32 * qt, s2, 32 * dt, lane);
+        const bf8 of = tr_frag32(Os, ROW_PITCH, 0, s2, 32 * dt, lane);
+        const bf8 qf = tr_frag32(Qs, ROW_PITCH, 0, s2, 32 * dt, lane);
         dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, pb, dV[dt], 0, 0, 0);
         dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, sb, dK[dt], 0, 0, 0);
       }
@@ -284,6 +287,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
       bf4 o = {f2bf(dP[4 * g4]), f2bf(dP[4 * g4 + 1]), f2bf(dP[4 * g4 + 2]), f2bf(dP[4 * g4 + 3])};
       *reinterpret_cast<bf4*>(Ds + key * DST_PITCH + (8 * g4 + 4 * hh) * 2) = o;
     }
+    if (qt + 1 < NT) park(cur ^ 1);       // the other buffer was last read before the previous iteration's first barrier
     __syncthreads();
     // dQ[q][d] = scale * sum_key dS[q][key] K[key][d] : 8 tiles of 16x16 per query tile, TPW per wave
 #pragma unroll
@@ -305,28 +309,46 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(AttnParams p) {
     }
     __syncthreads();
   }
-  bf16* dk = p.dqkv + ((size_t)b * S + key) * p.ld_qkv + p.H + h * 64;
-  bf16* dv = dk + p.H;
+  // dK, dV leave through LDS (the K image and the Q / dO tile buffers are free after the loop's last barrier): the
+  // accumulators hold 4 channels of one key per register quad -- written straight out that is 8-byte pieces of 32 different
+  // cache lines per store; from the [key][64] images every row leaves as one 128-byte line, and the column sums for the k | v
+  // bias gradients are 32 two-byte LDS reads per thread instead of ten 5-step shuffle trees per lane.
+  char* dKs = Ks;                 // [S][ROW_PITCH]
+  char* dVs = smem;               // [S][ROW_PITCH] over the four 32-row tile buffers (S <= 128)
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int d = 32 * dt + 8 * g4 + 4 * hh;
-      bf4 ok = {f2bf(dK[dt][4 * g4] * p.scale), f2bf(dK[dt][4 * g4 + 1] * p.scale), f2bf(dK[dt][4 * g4 + 2] * p.scale),
-                f2bf(dK[dt][4 * g4 + 3] * p.scale)};
-      bf4 ov = {f2bf(dV[dt][4 * g4]), f2bf(dV[dt][4 * g4 + 1]), f2bf(dV[dt][4 * g4 + 2]), f2bf(dV[dt][4 * g4 + 3])};
-      *reinterpret_cast<bf4*>(dk + d) = ok;
-      *reinterpret_cast<bf4*>(dv + d) = ov;
-      if (p.dbias_parts) {          // sums over this wave's 32 keys (the lanes of a half-wave), of the ROUNDED values
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float sk = bf2f(ok[e]), sv = bf2f(ov[e]);
-#pragma unroll
-          for (int o2 = 1; o2 < 32; o2 <<= 1) { sk += __shfl_xor(sk, o2, 64); sv += __shfl_xor(sv, o2, 64); }
-          if ((lane & 31) == 0) { atomicAdd(cb + 64 + d + e, sk); atomicAdd(cb + 128 + d + e, sv); }
-        }
-      }
+      const bf4 ok = {f2bf(dK[dt][4 * g4] * p.scale), f2bf(dK[dt][4 * g4 + 1] * p.scale), f2bf(dK[dt][4 * g4 + 2] * p.scale),
+                      f2bf(dK[dt][4 * g4 + 3] * p.scale)};
+      const bf4 ov = {f2bf(dV[dt][4 * g4]), f2bf(dV[dt][4 * g4 + 1]), f2bf(dV[dt][4 * g4 + 2]), f2bf(dV[dt][4 * g4 + 3])};
+      *reinterpret_cast<bf4*>(dKs + key * ROW_PITCH + d * 2) = ok;
+      *reinterpret_cast<bf4*>(dVs + key * ROW_PITCH + d * 2) = ov;
     }
+  __syncthreads();
+  {
+    bf16* dkg = p.dqkv + (size_t)b * S * p.ld_qkv + p.H + h * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {       // S*8 chunks of 16 bytes per tensor over 64*NT threads
+      const int c = tid + i * NTHR, row = c >> 3, ch = c & 7;
+      const uint4 kq = *reinterpret_cast<const uint4*>(dKs + row * ROW_PITCH + ch * 16);
+      const uint4 vq = *reinterpret_cast<const uint4*>(dVs + row * ROW_PITCH + ch * 16);
+      *reinterpret_cast<uint4*>(dkg + (size_t)row * p.ld_qkv + ch * 8) = kq;
+      *reinterpret_cast<uint4*>(dkg + (size_t)row * p.ld_qkv + p.H + ch * 8) = vq;
+    }
+  }
+  if (p.dbias_parts) {          // sums of the ROUNDED values: thread = (column, wave's 32 keys)
+    const int d = lane, k0 = 32 * w;
+    float sk = 0.f, sv = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      sk += bf2f(*reinterpret_cast<const bf16*>(dKs + (k0 + r) * ROW_PITCH + d * 2));
+      sv += bf2f(*reinterpret_cast<const bf16*>(dVs + (k0 + r) * ROW_PITCH + d * 2));
+    }
+    atomicAdd(cb + 64 + d, sk);
+    atomicAdd(cb + 128 + d, sv);
+  }
   if (p.dbias_parts) {
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {       // dq: rows of a 16x16 tile sit on lanes 0..15 of each 16-lane group
@@ -377,6 +399,10 @@ extern "C" int mmsim_attn_fwd(const void* qkv, int ld_qkv, const long long* mask
   return mmsim_check_launch("attn_fwd");
 }
 
+static size_t attn_bwd_lds(int S) {      // Q / dO tile pairs + K image + dS^T image + lse[S], delta[2][32], mask[S], bias sums[192]
+  return (size_t)4 * 32 * ROW_PITCH + (size_t)S * (ROW_PITCH + DST_PITCH) + (size_t)(2 * S + 64 + 192) * 4;
+}
+
 static int attn_bwd_impl(const void* qkv, int ld_qkv, const long long* mask, const void* ctx, const void* dctx, int ld_ctx,
                          const float* lse, void* dqkv, int B, int S, int heads, int H, float dropout_p, unsigned long long seed,
                          unsigned int stream_id, float* dbias_parts, void* stream) {
@@ -391,11 +417,11 @@ static int attn_bwd_impl(const void* qkv, int ld_qkv, const long long* mask, con
   p.thresh = dropout_p > 0.f ? (unsigned int)((double)dropout_p * 4294967296.0) : 0u;
   p.inv_keep = 1.0f / (1.0f - dropout_p);
   const int NT = S / 32;
-  const size_t lds = (size_t)S * (3 * ROW_PITCH + DST_PITCH) + 3 * S * 4 + 192 * 4;
+  const size_t lds = attn_bwd_lds(S);
   hipStream_t s = (hipStream_t)stream;
   static bool attr_done = false;
-  if (!attr_done) {   // S = 128 needs 66 KiB of dynamic LDS
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (3 * ROW_PITCH + DST_PITCH) + 3 * 128 * 4 + 192 * 4);
+  if (!attr_done) {   // S = 128 needs 48 KiB of dynamic LDS
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_bwd_lds(128));
     attr_done = true;
   }
   dim3 grid(B * heads), block(64 * NT);

@@ -95,3 +95,33 @@ __device__ __forceinline__ bool drop_keep16(uint32_t bits, int odd, uint32_t thr
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t stream, uint64_t idx, uint32_t thresh) {
   return drop_keep16(drop_bits(drop_key(seed, stream), idx >> 1), (int)(idx & 1), thresh);
 }
+
+// ---- transposing LDS reads (ds_read_b64_tr_b16, cdna_hip_programming.md T10): MFMA operand fragments whose reduction
+// index is the LDS image's ROW index.  EXEC must be all ones at every call.
+typedef s4 __attribute__((address_space(3))) * lds_s4_ptr;
+
+__device__ __forceinline__ bf8 tr_pair(const char* base, int off_lo, int row_step_bytes8) {
+  s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(base + off_lo));
+  s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(base + off_lo + row_step_bytes8));
+  s8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return __builtin_bit_cast(bf8, r);
+}
+
+// A-operand fragment of X^T for a 32x32x16 MFMA whose B operand is an accumulator tile:
+// image rows = reduction index (row0 + 16*s2 + ...), image cols = output rows (col0 + lane&31).
+__device__ __forceinline__ bf8 tr_frag32(const char* img, int pitch, int row0, int s2, int col0, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, hh = g >> 1;
+  const int row = row0 + 16 * s2 + 4 * hh + q;
+  const int col = col0 + 16 * (g & 1) + 4 * p;
+  return tr_pair(img, row * pitch + col * 2, 8 * pitch);
+}
+// operand fragment for a 16x16x32 MFMA: image rows = reduction index (row0 + 8*(lane>>4) + ...), cols col0 + lane&15
+__device__ __forceinline__ bf8 tr_frag16(const char* img, int pitch, int row0, int col0, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int row = row0 + 8 * g + q;
+  const int col = col0 + 4 * p;
+  return tr_pair(img, row * pitch + col * 2, 4 * pitch);
+}
+

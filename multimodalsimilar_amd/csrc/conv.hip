@@ -857,110 +857,175 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16* __re
 
 // ------------------------------------------------------------------ stem conv 3x3 s2 p1 on the NCHW fp32 image
 struct StemGeom { int B, Hi, Wi, Ho, Wo, Co; FastDiv d_wo, d_ho; };
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, bf16* z, float* parts, StemGeom g,
-                                                       int pix_per_block) {
-  __shared__ float lds[256 * 16];
-  __shared__ float wl[27 * 64];              // [tap][co], Co <= 64
-  for (int i = threadIdx.x; i < 27 * g.Co; i += 256) { const int co = i / 27, t = i % 27; wl[t * g.Co + co] = w[i]; }
-  __syncthreads();
-  const CgMap m = cg_map(g.Co);
-  float st[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) st[i] = 0.f;
-  const int npix = g.B * g.Ho * g.Wo;
-  if (m.active) {
-    const int c0 = m.cg * 8;
-    const int p0 = blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
-    for (int p = p0 + m.rl; p < p1; p += m.nr) {
-      int wo, ho, b, rowi;
-      fdivmod((unsigned int)p, g.d_wo, rowi, wo);
-      fdivmod((unsigned int)rowi, g.d_ho, b, ho);
-      float acc[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-      // all 27 image taps requested together, bounds-masked (clamped address, value zeroed): no per-load branches
-      float v[27];
-#pragma unroll
-      for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int hi = ho * 2 - 1 + kh;
-          const float* xrow = x + (((size_t)b * 3 + ci) * g.Hi + clampi(hi, 0, g.Hi - 1)) * g.Wi;
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int wi = wo * 2 - 1 + kw;
-            const unsigned int t = reinterpret_cast<const unsigned int*>(xrow)[clampi(wi, 0, g.Wi - 1)];
-            v[ci * 9 + kh * 3 + kw] = __uint_as_float(t & ((hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi) ? 0xffffffffu : 0u));
-          }
-        }
-#pragma unroll
-      for (int t = 0; t < 27; ++t) {
-        const float* wp = wl + t * g.Co + c0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += v[t] * wp[e];
-      }
-      const uint4 o = pack8(acc);
-      *reinterpret_cast<uint4*>(z + (size_t)p * g.Co + c0) = o;
-      float r[8];
-      unpack8(o, r);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { st[e] += r[e]; st[8 + e] += r[e] * r[e]; }
-    }
-  }
-  block_reduce_store<16>(st, m, lds, parts + (size_t)blockIdx.x * 2 * g.Co, (size_t)g.Co);
-}
+// ---- the stem on the matrix cores.  K = 27 taps (+5 zero) is ONE 16x16x32 bf16 MFMA per 16 pixels x 16 channels, so the
+// conv costs its image gathers and nothing else (the VALU version spent 216 FMAs + 54 LDS weight reads per pixel-octet and
+// gathered every pixel's 27 taps once per channel octet).
+// Forward: D^T[co][p] = W[co][tap] * xcol^T[tap][p].  Lane (p = lane & 15, kg = lane >> 4) gathers taps 8kg .. 8kg+7 of pixel p
+// straight from the NCHW fp32 image (clamped address, AND-masked value), rounds them to bf16: that IS the second operand.
+// First operand: W rows, register-resident.  Result: lane holds channels 16ct + 4kg .. +3 of pixel p -> one 8-byte store.
+__device__ __forceinline__ void stem_tap(int tap, int& ci, int& kh, int& kw) { ci = tap / 9; kh = (tap - ci * 9) / 3; kw = tap - ci * 9 - kh * 3; }
 
-// dW[co][ci][kh][kw] += sum_p dz[p,co] * x[p @ tap]; thread = (pixel lane, tap, octet): SW_LANES pixel lanes share a
-// block's pixel slab (a single lane is latency-bound: 2 k trips of dependent round trips), reduced through LDS at the end
-#define SW_LANES 4
-__global__ __launch_bounds__(27 * 8 * SW_LANES) void stem_wgrad_kernel(const bf16* dz, const float* x, float* dw, StemGeom g, int pix_per_block) {
-  __shared__ float red[SW_LANES][27 * 8 * 8];
-  const int G = g.Co >> 3, per = 27 * G;
-  const int pl = threadIdx.x / per, t = threadIdx.x - pl * per;
-  const bool active = pl < SW_LANES;
-  const int tap = t / G, cg = t % G, c0 = cg * 8;
-  const int ci = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
-  float acc[8];
+template <int CT>
+__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, bf16* z, float* parts,
+                                                            StemGeom g, int pix_per_block) {
+  __shared__ float red[4][128];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, kg = lane >> 4;
+  bf8 wf[CT], wl[CT];            // fp32 weights and pixels as bf16 hi + lo pairs (hi*hi + lo*hi + hi*lo): fp32-accurate products
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tap = 8 * kg + j, co = 16 * ct + pl;
+      const float v = (tap < 27 && co < g.Co) ? w[co * 27 + tap] : 0.f;
+      wf[ct][j] = f2bf(v);
+      wl[ct][j] = f2bf(v - bf2f(wf[ct][j]));
+    }
+  float st[CT][4], sq[CT][4];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { st[ct][e] = 0.f; sq[ct][e] = 0.f; }
   const int npix = g.B * g.Ho * g.Wo;
   const int p0 = blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
-  if (active)
-  for (int pb = p0 + pl * 8; pb < p1; pb += 8 * SW_LANES) {         // 8 pixels per trip: 8 + 8 independent (bounds-masked) loads in flight
-    float v[8];
-    uint4 dr[8];
+  const size_t plane = (size_t)g.Hi * g.Wi;
+  for (int pb = p0 + wv * 16; pb < p1; pb += 64) {          // wave-uniform trip count: the MFMA needs every lane
+    const bool pv = pb + pl < p1;
+    const int p = min(pb + pl, p1 - 1);
+    int wo, ho, b, rowi;
+    fdivmod((unsigned int)p, g.d_wo, rowi, wo);
+    fdivmod((unsigned int)rowi, g.d_ho, b, ho);
+    const float* xb = x + (size_t)b * 3 * plane;
+    bf8 xf, xl;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int p = min(pb + q, p1 - 1);
+    for (int j = 0; j < 8; ++j) {
+      int ci, kh, kw;
+      stem_tap(min(8 * kg + j, 26), ci, kh, kw);
+      const int hi = ho * 2 - 1 + kh, wi = wo * 2 - 1 + kw;
+      const unsigned int t = reinterpret_cast<const unsigned int*>(xb + ci * plane)[(size_t)clampi(hi, 0, g.Hi - 1) * g.Wi + clampi(wi, 0, g.Wi - 1)];
+      const bool ok = 8 * kg + j < 27 && hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi;
+      const float v = __uint_as_float(t & (ok ? 0xffffffffu : 0u));
+      xf[j] = f2bf(v);
+      xl[j] = f2bf(v - bf2f(xf[j]));
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ct], xf, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct], xl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct], xf, acc, 0, 0, 0);
+      const bf4 o = {f2bf(acc[0]), f2bf(acc[1]), f2bf(acc[2]), f2bf(acc[3])};
+      const int c0 = 16 * ct + 4 * kg;
+      if (pv && c0 < g.Co) {
+        *reinterpret_cast<bf4*>(z + (size_t)p * g.Co + c0) = o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float r = bf2f(o[e]); st[ct][e] += r; sq[ct][e] += r * r; }
+      }
+    }
+  }
+  // BatchNorm statistics of the ROUNDED outputs: over the 16 pixel lanes, then over the block's waves, one slab row per block
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = st[ct][e], q = sq[ct][e];
+#pragma unroll
+      for (int o2 = 1; o2 < 16; o2 <<= 1) { a += __shfl_xor(a, o2, 64); q += __shfl_xor(q, o2, 64); }
+      if (pl == 0) { red[wv][16 * ct + 4 * kg + e] = a; red[wv][64 + 16 * ct + 4 * kg + e] = q; }
+    }
+  __syncthreads();
+  if (tid < 128) {
+    const int co = tid & 63, which = tid >> 6;
+    if (co < g.Co) parts[(size_t)blockIdx.x * 2 * g.Co + which * g.Co + co] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  }
+}
+
+// Weight gradient: D[tap][co] = sum_p x^T[tap][p] dz[p][co], 32 pixels per MFMA.  Each wave parks a chunk's taps tap-major
+// ([32 taps][32 pixels] bf16: row reads are the first operand) and its dz rows pixel-major ([32 pixels][Co]: the second operand
+// through the transposing read), so dz is read from HBM once (the VALU version re-read every dz row once per tap).
+template <int CT>
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const bf16* __restrict__ dz, const float* __restrict__ x, float* dw, StemGeom g,
+                                                              int pix_per_block) {
+  constexpr int XP = 80, ZP = 144;             // row pitches in bytes: 32 pixels (64 B) + pad; <= 64 channels (128 B) + pad
+  __shared__ __attribute__((aligned(16))) char xs_all[4][2 * 32 * XP];       // bf16 hi image, then the lo image (x = hi + lo: fp32-accurate)
+  __shared__ __attribute__((aligned(16))) char zs_all[4][32 * ZP];
+  __shared__ float red[32 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, half = lane >> 5, kg = lane >> 4;
+  char* xs = xs_all[wv];
+  char* zs = zs_all[wv];
+  for (int i = tid; i < 32 * 64; i += 256) red[i] = 0.f;
+  for (int i = lane; i < 2 * 32 * XP / 4; i += 64) reinterpret_cast<unsigned int*>(xs)[i] = 0u;   // tap rows 27..31 stay zero
+  for (int i = lane; i < 32 * ZP / 4; i += 64) reinterpret_cast<unsigned int*>(zs)[i] = 0u;       // channel columns >= Co stay zero
+  f4 acc[2][CT];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[tt][ct] = f4{0.f, 0.f, 0.f, 0.f};
+  const int npix = g.B * g.Ho * g.Wo, G = g.Co >> 3;
+  const int p0 = blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
+  const size_t plane = (size_t)g.Hi * g.Wi;
+  __syncthreads();
+  for (int cb = p0; cb < p1; cb += 128) {            // block-uniform trip count (barriers inside); a wave past the end parks zeros
+    const int pb = cb + wv * 32;
+    {   // taps: lane = (pixel, half of the taps): 14 masked gathers
+      const int p = min(pb + pl, p1 - 1);
       int wo, ho, b, rowi;
       fdivmod((unsigned int)p, g.d_wo, rowi, wo);
       fdivmod((unsigned int)rowi, g.d_ho, b, ho);
-      const int hi = ho * 2 - 1 + kh, wi = wo * 2 - 1 + kw;
-      const unsigned int t2 = reinterpret_cast<const unsigned int*>(x)[(((size_t)b * 3 + ci) * g.Hi + clampi(hi, 0, g.Hi - 1)) * g.Wi + clampi(wi, 0, g.Wi - 1)];
-      v[q] = __uint_as_float(t2 & ((pb + q < p1 && hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi) ? 0xffffffffu : 0u));
-      dr[q] = *reinterpret_cast<const uint4*>(dz + (size_t)p * g.Co + c0);
+      const float* xb = x + (size_t)b * 3 * plane;
+      float v[14];
+#pragma unroll
+      for (int j = 0; j < 14; ++j) {
+        int ci, kh, kw;
+        stem_tap(min(half * 14 + j, 26), ci, kh, kw);
+        const int hi = ho * 2 - 1 + kh, wi = wo * 2 - 1 + kw;
+        const unsigned int t = reinterpret_cast<const unsigned int*>(xb + ci * plane)[(size_t)clampi(hi, 0, g.Hi - 1) * g.Wi + clampi(wi, 0, g.Wi - 1)];
+        const bool ok = half * 14 + j < 27 && hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi;
+        v[j] = __uint_as_float(t & (ok ? 0xffffffffu : 0u));
+      }
+      // dz rows: 32 x G chunks of 16 bytes over the wave (a pixel past the end contributes zeros, whatever its taps were)
+      uint4 dr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = min(lane + 64 * i, 32 * G - 1), row = c / G, ch = c - row * G;
+        dr[i] = ld16_masked(dz + (size_t)min(pb + row, p1 - 1) * g.Co + ch * 8, pb + row < p1);
+      }
+#pragma unroll
+      for (int j = 0; j < 14; ++j) {
+        const bf16 hi16 = f2bf(v[j]);
+        *reinterpret_cast<bf16*>(xs + (half * 14 + j) * XP + pl * 2) = hi16;
+        *reinterpret_cast<bf16*>(xs + 32 * XP + (half * 14 + j) * XP + pl * 2) = f2bf(v[j] - bf2f(hi16));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i, row = c / G, ch = c - row * G;
+        if (c < 32 * G) *reinterpret_cast<uint4*>(zs + row * ZP + ch * 16) = dr[i];
+      }
     }
+    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      float d[8];
-      unpack8(dr[q], d);
+    for (int ct = 0; ct < CT; ++ct) {
+      const bf8 zf = tr_frag16(zs, ZP, 0, 16 * ct, lane);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += v[q] * d[e];
+      for (int tt = 0; tt < 2; ++tt) {
+        const bf8 xf = *reinterpret_cast<const bf8*>(xs + (16 * tt + (lane & 15)) * XP + kg * 16);
+        const bf8 xl = *reinterpret_cast<const bf8*>(xs + 32 * XP + (16 * tt + (lane & 15)) * XP + kg * 16);
+        acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, zf, acc[tt][ct], 0, 0, 0);
+        acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, zf, acc[tt][ct], 0, 0, 0);
+      }
     }
+    __syncthreads();
   }
-  if (active) {
+  // acc[tt][ct][e] = D[tap 16tt + 4kg + e][co 16ct + (lane & 15)]: block sum in LDS, then one atomic per weight per block
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[pl][t * 8 + e] = acc[e];
-  }
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(red + (16 * tt + 4 * kg + e) * 64 + 16 * ct + (lane & 15), acc[tt][ct][e]);
   __syncthreads();
-  if (active && pl == 0) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float sum = 0.f;
-#pragma unroll
-      for (int l = 0; l < SW_LANES; ++l) sum += red[l][t * 8 + e];
-      atomicAdd(dw + (size_t)(c0 + e) * 27 + tap, sum);
-    }
+  for (int i = tid; i < 27 * g.Co; i += 256) {
+    const int co = i / 27, tap = i - co * 27;
+    atomicAdd(dw + i, red[tap * 64 + co]);
   }
 }
 
@@ -1257,10 +1322,14 @@ extern "C" int mmsim_stem_fwd(const float* x, const float* w, void* z, float* su
   MMSIM_REQUIRE(Co <= 64, "stem_fwd: at most 64 output channels");
   StemGeom g; g.B = B; g.Hi = Hi; g.Wi = Wi; g.Ho = (Hi + 2 - 3) / 2 + 1; g.Wo = (Wi + 2 - 3) / 2 + 1; g.Co = Co; g.d_wo = make_fastdiv(g.Wo); g.d_ho = make_fastdiv(g.Ho);
   const int npix = B * g.Ho * g.Wo;
-  const int ppb = rows_per_block_for(npix, nr_of(Co));
+  const int ppb = ((npix + 4095) / 4096 + 63) / 64 * 64;          // <= 4096 blocks, whole 16-pixel x 4-wave trips
   const int nparts = (npix + ppb - 1) / ppb;
   REQ_SCRATCH((size_t)nparts * 2 * Co, "stem_fwd");
-  hipLaunchKernelGGL(stem_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)z, scratch, g, ppb);
+  const int CT = (Co + 15) / 16;
+  if (CT == 1) hipLaunchKernelGGL((stem_fwd_mfma_kernel<1>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)z, scratch, g, ppb);
+  else if (CT == 2) hipLaunchKernelGGL((stem_fwd_mfma_kernel<2>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)z, scratch, g, ppb);
+  else if (CT == 3) hipLaunchKernelGGL((stem_fwd_mfma_kernel<3>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)z, scratch, g, ppb);
+  else hipLaunchKernelGGL((stem_fwd_mfma_kernel<4>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)z, scratch, g, ppb);
   launch_reduce(scratch, nparts, 2 * Co, sums, 1, (hipStream_t)stream);
   return mmsim_check_launch("stem_fwd");
 }
@@ -1270,8 +1339,13 @@ extern "C" int mmsim_stem_wgrad(const void* dz, const float* x, float* dw, int B
   MMSIM_REQUIRE(Co <= 64, "stem_wgrad: at most 64 output channels");
   StemGeom g; g.B = B; g.Hi = Hi; g.Wi = Wi; g.Ho = (Hi + 2 - 3) / 2 + 1; g.Wo = (Wi + 2 - 3) / 2 + 1; g.Co = Co; g.d_wo = make_fastdiv(g.Wo); g.d_ho = make_fastdiv(g.Ho);
   const int npix = B * g.Ho * g.Wo;
-  const int ppb = 2048;
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3((npix + ppb - 1) / ppb), dim3(27 * (Co / 8) * SW_LANES), 0, (hipStream_t)stream, (const bf16*)dz, x, dw, g, ppb);
+  const int ppb = ((npix + 511) / 512 + 127) / 128 * 128;         // <= 512 blocks (each ends in 27*Co atomics), whole 4-wave x 32-pixel trips
+  const dim3 grid((npix + ppb - 1) / ppb), block(256);
+  const int CT = (Co + 15) / 16;
+  if (CT == 1) hipLaunchKernelGGL((stem_wgrad_mfma_kernel<1>), grid, block, 0, (hipStream_t)stream, (const bf16*)dz, x, dw, g, ppb);
+  else if (CT == 2) hipLaunchKernelGGL((stem_wgrad_mfma_kernel<2>), grid, block, 0, (hipStream_t)stream, (const bf16*)dz, x, dw, g, ppb);
+  else if (CT == 3) hipLaunchKernelGGL((stem_wgrad_mfma_kernel<3>), grid, block, 0, (hipStream_t)stream, (const bf16*)dz, x, dw, g, ppb);
+  else hipLaunchKernelGGL((stem_wgrad_mfma_kernel<4>), grid, block, 0, (hipStream_t)stream, (const bf16*)dz, x, dw, g, ppb);
   return mmsim_check_launch("stem_wgrad");
 }
 
