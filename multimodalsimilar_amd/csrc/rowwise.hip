@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* dout, con
                                                            const float* gamma, float* dword, float* dpos, float* dtype,
                                                            float* dgamma, float* dbeta, int B, int S, int H, float eps,
                                                            int bchunk, Drop dr) {
+  __shared__ __attribute__((aligned(16))) float rowbuf[4][MAXC * 256];       // one d(embedding) row per wave
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int gw = blockIdx.x * 4 + wv;
   const int nchunks = (B + bchunk - 1) / bchunk;
@@ -145,13 +146,25 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* dout, con
       if (col < H) {
         const float4 de = make_float4(rstd * (g[c].x - s1 - v[c].x * s2), rstd * (g[c].y - s1 - v[c].y * s2),
                                       rstd * (g[c].z - s1 - v[c].z * s2), rstd * (g[c].w - s1 - v[c].w * s2));
-        float* dw = dword + (size_t)id * H + col;
-        atomicAdd(dw, de.x); atomicAdd(dw + 1, de.y); atomicAdd(dw + 2, de.z); atomicAdd(dw + 3, de.w);
+        *reinterpret_cast<float4*>(rowbuf[wv] + col) = de;
         apos[c].x += de.x; apos[c].y += de.y; apos[c].z += de.z; apos[c].w += de.w;
         if (tt == 0) { at0[c].x += de.x; at0[c].y += de.y; at0[c].z += de.z; at0[c].w += de.w; }
         else { at1[c].x += de.x; at1[c].y += de.y; at1[c].z += de.z; at1[c].w += de.w; }
       }
     }
+    // scatter-add of the row into the word-embedding gradient: through the wave's LDS row so that ONE atomic instruction
+    // covers 256 contiguous bytes (lane = column); straight from the float4 registers every instruction touched 4 bytes
+    // out of every 16 across eight cache lines, four times over
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* dw = dword + (size_t)id * H;
+#pragma unroll
+    for (int j = 0; j < MAXC * 4; ++j) {
+      const int col = j * 64 + lane;
+      if (col < H) atomicAdd(dw + col, rowbuf[wv][col]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
@@ -421,10 +434,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* x, int ld, floa
   const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (col < N) {
-    for (int row = r0 + wv; row < r1; row += 4) {
-      const bf8 v = *reinterpret_cast<const bf8*>(x + (size_t)row * ld + col);
+    // 8 rows per trip: eight independent 16-byte loads in flight per lane (one load per trip left the pass latency-bound);
+    // rows past the end re-read the last row (valid address) and are AND-masked to zero
+    for (int row = r0 + wv; row < r1; row += 32) {
+      uint4 v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+      for (int u = 0; u < 8; ++u) {
+        const int rr = row + 4 * u;
+        const uint4 t = *reinterpret_cast<const uint4*>(x + (size_t)min(rr, r1 - 1) * ld + col);
+        const unsigned int msk = rr < r1 ? 0xffffffffu : 0u;
+        v[u] = make_uint4(t.x & msk, t.y & msk, t.z & msk, t.w & msk);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bf8 b = __builtin_bit_cast(bf8, v[u]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += bf2f(b[j]);
+      }
     }
   }
 #pragma unroll
@@ -571,7 +597,7 @@ extern "C" int mmsim_ln_bwd(const void* dh_a, const void* dh_b, const void* y, c
 extern "C" int mmsim_colsum_bf16(const void* x, int ld, float* out, int M, int N, void* stream) {
   MMSIM_REQUIRE(x && out && M > 0 && N > 0, "colsum: bad arguments");
   MMSIM_REQUIRE(ld % 8 == 0 && ld >= ((N + 7) & ~7), "colsum: ld must be a multiple of 8 covering N rounded up to 8");
-  const int rpb = 256;
+  const int rpb = M >= 8192 ? 512 : 256;      // fewer, longer blocks: every block ends in one atomic per column
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
                      (const bf16*)x, ld, out, M, N, rpb);
   return mmsim_check_launch("colsum");

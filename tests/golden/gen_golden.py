@@ -232,8 +232,34 @@ def gen_multilabel():
     npz("nlp_multilabel.npz", **out)
 
 
+def gen_preprocess():
+    """Input stage: Pillow itself (the library under torchvision's Resize in the reference's transform) resizes
+    seeded uint8 images; the crop / ToTensor / Normalize steps of the published timm eval pipeline are applied with torch
+    exactly as torchvision applies them.  Stored: inputs, Pillow's resized uint8 images, the final fp32 tensors."""
+    import math
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    cases = [(37, 53, 32, 1.0), (64, 48, 32, 0.875), (75, 50, 64, 1.0), (40, 40, 64, 1.0), (131, 97, 32, 1.0)]   # H, W, S, crop_pct
+    out = {"cases": np.array(cases, np.float64), "pillow": np.array([int(x) for x in Image.__version__.split(".")])}
+    for i, (H, W, S, cp) in enumerate(cases):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        # smooth half of the cases: real photographs are not white noise, and clipping behaves differently on them
+        if i % 2 == 0:
+            img = np.asarray(Image.fromarray(img).resize((max(2, W // 8), max(2, H // 8))).resize((W, H), Image.BICUBIC))
+        size = int(math.floor(S / cp))
+        ow, oh = (size, int(size * H / W)) if W <= H else (int(size * W / H), size)          # torchvision Resize(int)
+        r = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BICUBIC))
+        top, left = int(round((oh - S) / 2.0)), int(round((ow - S) / 2.0))                    # torchvision CenterCrop
+        c = torch.from_numpy(r[top:top + S, left:left + S].copy()).permute(2, 0, 1).contiguous()
+        t = c.to(torch.float32).div(255)                                                       # ToTensor
+        t = (t - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)           # Normalize
+        out[f"img{i}"], out[f"resized{i}"], out[f"out{i}"] = img, r, t
+    npz("preprocess.npz", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1] if len(sys.argv) > 1 else None
-    for fn in (gen_arcface, gen_nlp, gen_glue, gen_optim, gen_multilabel):
+    for fn in (gen_arcface, gen_nlp, gen_glue, gen_optim, gen_multilabel, gen_preprocess):
         if only is None or fn.__name__ == "gen_" + only:
             fn()

@@ -139,3 +139,27 @@ def test_no_product_module_imports_the_oracle():
     for f in files:
         src = open(f).read()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_preprocess_host_kernels_equal_the_oracles_and_reject_bad_input():
+    """Host half of the input stage: the fixed-point resampling kernels built vectorised in the product equal the oracle's
+    scalar restatement of Pillow's precompute_coeffs (itself pinned to Pillow), and argument errors raise before any launch."""
+    import numpy as np
+    import pytest
+    from multimodalsimilar_amd import preprocess as PP
+    from oracle import preprocess_ref as PR
+    for a, b in [(53, 20), (48, 320), (500, 320), (23, 224), (100, 100), (17, 31), (1024, 224), (7, 3)]:
+        ks, bo, kk = PR.resample_coeffs(a, b)
+        ks2, b2, k2 = PP.bicubic_kernels(a, b)
+        assert ks == ks2 and np.array_equal(bo, b2) and np.array_equal(kk, k2)
+    with pytest.raises(ValueError):
+        PP.create_transform(input_size=(3, 320, 300))
+    with pytest.raises(ValueError):
+        PP.create_transform(interpolation="bilinear")
+    with pytest.raises(NotImplementedError):
+        PP.create_transform(is_training=True)
+    t = PP.create_transform(input_size=(3, 320, 320), interpolation="bicubic", mean=(0.485, 0.456, 0.406),
+                            std=(0.229, 0.224, 0.225), crop_pct=1.0, device="cpu")       # the reference's config, multimodal_infer.py:86-90
+    assert t.size == 320 and t.scale_size == 320
+    with pytest.raises(PP.MmsimError):
+        t(np.zeros((400, 400, 3), np.uint8))          # no CPU path

@@ -180,3 +180,27 @@ def test_search_oracle_properties():
     D2, I2 = search_ref.search_inner_product(x[:2], x[:3], 5)
     assert np.all(I2[:, 3:] == -1) and np.all(np.isinf(D2[:, 3:]))
     assert np.allclose(np.linalg.norm(search_ref.normalize_l2(x), axis=1), 1.0, atol=1e-6)
+
+
+def test_preprocess_oracle_matches_pillow_fixture(golden_dir):
+    """Input stage oracle vs the fixture produced by Pillow + the torchvision steps (gen_golden.py gen_preprocess): the
+    resized uint8 images bit for bit, the normalised tensors exactly."""
+    from oracle import preprocess_ref as P
+    g = _load(golden_dir, "preprocess.npz")
+    for i, (H, W, S, cp) in enumerate(g["cases"]):
+        img, S = g[f"img{i}"], int(S)
+        oh, ow = g[f"resized{i}"].shape[:2]
+        assert P.resize_target(int(H), int(W), int(np.floor(S / cp))) == (ow, oh)
+        assert np.array_equal(P.resize_bicubic_u8(img, ow, oh), g[f"resized{i}"])
+        assert np.array_equal(P.eval_transform(img, S, cp), g[f"out{i}"])
+
+
+def test_preprocess_oracle_matches_installed_pillow():
+    """The same pin live against the Pillow in this image, on shapes the fixture does not hold (up- and down-scaling,
+    identity axis, extreme ratios)."""
+    Image = pytest.importorskip("PIL.Image")
+    from oracle import preprocess_ref as P
+    rng = np.random.default_rng(3)
+    for H, W, ow, oh in [(33, 47, 20, 14), (48, 36, 96, 128), (90, 60, 60, 90), (23, 23, 64, 64), (200, 150, 75, 56), (31, 17, 17, 31)]:
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        assert np.array_equal(P.resize_bicubic_u8(img, ow, oh), np.asarray(Image.fromarray(img).resize((ow, oh), Image.BICUBIC)))
