@@ -41,7 +41,8 @@ int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, const void* 
                     void* aux_out, int ld_aux, float alpha, int split_k, int accumulate, void* stream);
 
 /* 1x1 conv whose input is the previous BatchNorm + SiLU (+ squeeze-excite gate) applied while the operand is
- * staged: x -> silu(xf_scale[c] x + xf_shift[c]) * xf_gate[pixel / xf_hw, c]  (gate may be NULL).
+ * staged: x -> silu(xf_scale[c] x + xf_shift[c]) * xf_gate[pixel / xf_hw, c]  (gate may be NULL); with xf_scale = xf_shift =
+ * NULL the operand is already activated (mmsim_pool_bn_act_store) and only x -> x * gate remains.
  *   xf_operand 1 (forward): C[P,Cout] = xf(A)[P,Cin] B[Cout,Cin]^T;  2 (wgrad): C[Cout,Cin] (+)= A[P,Cout]^T xf(B)[P,Cin].
  * Replaces timm's conv_pwl / conv_pw after bn+act+se inside the MBConv blocks under cv_classifier.py:49. */
 int mmsim_gemm_bf16_xf(int xf_operand, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
@@ -143,6 +144,11 @@ int mmsim_bn_apply(const void* z, const float* scale, const float* shift, const 
 /* out[b,c] = mul * sum_hw act(scale*z+shift) * (other ? other : 1): SE squeeze / global pool (mul = 1/HW), SE dgate. */
 int mmsim_pool_bn_act(const void* z, const float* scale, const float* shift, const void* other, float* out, int B,
                       int HW, int C, int act_silu, float mul, void* stream);
+/* The SE squeeze that also keeps the activated tensor: act_out [B*HW][C] bf16 = silu(scale*z+shift), out = mul * sum_hw of it.
+ * The projection conv and its weight gradient then take act_out with a gate-only operand transform (mmsim_gemm_bf16_xf /
+ * _bnstats with xf_scale = xf_shift = NULL): one multiply per element instead of BN + SiLU + gate in the GEMM's staging. */
+int mmsim_pool_bn_act_store(const void* z, const float* scale, const float* shift, void* act_out, float* out, int B,
+                            int HW, int C, float mul, void* stream);
 
 /* Backward of the SE squeeze and, in the same pass over (z, dy), the partial sums from which the depthwise BatchNorm's
  * backward batch sums follow once the SE backward has produced dsq (timm SqueezeExcite + bn2 + act under cv_classifier.py:49):

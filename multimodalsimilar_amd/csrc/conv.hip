@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* z, const floa
 // out[b,c] = mul * sum_hw act(scale*z+shift)[b,hw,c] * (other ? other[b,hw,c] : 1)      (fp32 [B,C])
 __global__ __launch_bounds__(256) void pool_bn_act_kernel(const bf16* __restrict__ z, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const bf16* __restrict__ other,
-                                                          float* out, int HW, int C, int act, float mul, int rows_per_z) {
+                                                          float* out, int HW, int C, int act, float mul, int rows_per_z,
+                                                          bf16* __restrict__ act_out) {
   __shared__ float lds[256 * 8];
   const CgMap m = pool_map(C);
   const int lc = threadIdx.x % m.G;
@@ -216,8 +217,12 @@ __global__ __launch_bounds__(256) void pool_bn_act_kernel(const bf16* __restrict
 #pragma unroll
           for (int e = 0; e < 8; ++e) { float y = f[e] * sc[e] + sh[e]; if (act) y = silu_f(y); acc[e] += y * o[e]; }
         } else {
+          float y8[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { float y = f[e] * sc[e] + sh[e]; if (act) y = silu_f(y); acc[e] += ok[q] ? y : 0.f; }
+          for (int e = 0; e < 8; ++e) { float y = f[e] * sc[e] + sh[e]; if (act) y = silu_f(y); y8[e] = y; acc[e] += ok[q] ? y : 0.f; }
+          // the activated tensor kept for the projection conv (its operand is then a2 * gate: one multiply per element in
+          // the GEMM's staging instead of BN + SiLU + gate, which made those products VALU-bound)
+          if (act_out && ok[q]) *reinterpret_cast<uint4*>(act_out + ((size_t)b * HW + r + q * m.nr) * C + m.cg * 8) = pack8(y8);
         }
       }
     }
@@ -606,17 +611,23 @@ __global__ __launch_bounds__(256) DW_OCC void dwconv_fwd_kernel(const bf16* __re
           }
         }
       } else {
-#pragma unroll 1
-        for (int kh = 0; kh < K; ++kh) {
+        // one kernel row per trip, the NEXT row's chunks requested before this row's FMAs (a trip used to be: request,
+        // wait a full L2 round trip, compute -- K dependent round trips per item at two waves per SIMD)
+        auto load_row = [&](int kh, uint4 (&dst)[NIN]) {
           const int hi = ho * S - PAD + kh;
           const bool hv = hi >= 0 && hi < g.Hi;
           const bf16* arow = a + ((size_t)b * g.Hi + clampi(hi, 0, g.Hi - 1)) * g.Wi * g.C + m.cg * 8;
-          uint4 raw[NIN];
 #pragma unroll
           for (int x = 0; x < NIN; ++x) {
             const int wi = wo0 * S - PAD + x;
-            raw[x] = ld16_masked(arow + (size_t)clampi(wi, 0, g.Wi - 1) * g.C, hv && wi >= 0 && wi < g.Wi);
+            dst[x] = ld16_masked(arow + (size_t)clampi(wi, 0, g.Wi - 1) * g.C, hv && wi >= 0 && wi < g.Wi);
           }
+        };
+        uint4 raw[NIN], nxt[NIN];
+        load_row(0, raw);
+#pragma unroll 1
+        for (int kh = 0; kh < K; ++kh) {
+          if (kh + 1 < K) load_row(kh + 1, nxt);
           float in[NIN][8];
 #pragma unroll
           for (int x = 0; x < NIN; ++x) unpack8(raw[x], in[x]);
@@ -629,6 +640,8 @@ __global__ __launch_bounds__(256) DW_OCC void dwconv_fwd_kernel(const bf16* __re
 #pragma unroll
               for (int e = 0; e < 8; ++e) acc[j][e] += in[j * S + kw][e] * w[e];
           }
+#pragma unroll
+          for (int x = 0; x < NIN; ++x) raw[x] = nxt[x];
         }
       }
 #pragma unroll
@@ -711,17 +724,21 @@ __global__ __launch_bounds__(256) DW_OCC void dwconv_bwd_data_kernel(const bf16*
             }
           }
         } else {
-#pragma unroll 1
-        for (int kh = 0; kh < K; ++kh) {
+        auto load_row = [&](int kh, uint4 (&dst)[NIN]) {      // next row requested ahead of this row's FMAs (see dwconv_fwd)
           const int ho = hi + PAD - kh;
           const bool hv = ho >= 0 && ho < g.Ho;
           const bf16* drow = dz + ((size_t)b * g.Ho + clampi(ho, 0, g.Ho - 1)) * g.Wo * g.C + c0;
-          uint4 raw[NIN];
 #pragma unroll
           for (int x = 0; x < NIN; ++x) {
             const int wo = wi0 - PAD + x;
-            raw[x] = ld16_masked(drow + (size_t)clampi(wo, 0, g.Wo - 1) * g.C, hv && wo >= 0 && wo < g.Wo);
+            dst[x] = ld16_masked(drow + (size_t)clampi(wo, 0, g.Wo - 1) * g.C, hv && wo >= 0 && wo < g.Wo);
           }
+        };
+        uint4 raw[NIN], nxt[NIN];
+        load_row(0, raw);
+#pragma unroll 1
+        for (int kh = 0; kh < K; ++kh) {
+          if (kh + 1 < K) load_row(kh + 1, nxt);
           float in[NIN][8];
 #pragma unroll
           for (int x = 0; x < NIN; ++x) unpack8(raw[x], in[x]);
@@ -734,6 +751,8 @@ __global__ __launch_bounds__(256) DW_OCC void dwconv_bwd_data_kernel(const bf16*
 #pragma unroll
               for (int e = 0; e < 8; ++e) acc[j][e] += in[j + K - 1 - kw][e] * w[e];
           }
+#pragma unroll
+          for (int x = 0; x < NIN; ++x) raw[x] = nxt[x];
         }
         }
       } else {
@@ -1138,8 +1157,8 @@ extern "C" int mmsim_bn_apply(const void* z, const float* scale, const float* sh
   return mmsim_check_launch("bn_apply");
 }
 
-extern "C" int mmsim_pool_bn_act(const void* z, const float* scale, const float* shift, const void* other, float* out, int B,
-                                 int HW, int C, int act_silu, float mul, void* stream) {
+static int pool_bn_act_impl(const void* z, const float* scale, const float* shift, const void* other, float* out, int B,
+                            int HW, int C, int act_silu, float mul, void* act_out, void* stream) {
   MMSIM_REQUIRE(z && scale && shift && out && B > 0 && HW > 0, "pool_bn_act: bad arguments"); REQ_C8(C, "pool_bn_act");
   // large feature maps: split the HW range over blockIdx.z so that more than B blocks stream (few adders per output)
   int nz = 1;
@@ -1148,8 +1167,19 @@ extern "C" int mmsim_pool_bn_act(const void* z, const float* scale, const float*
   const int rpz = (HW + nz - 1) / nz;
   if (nz > 1) (void)hipMemsetAsync(out, 0, (size_t)B * C * sizeof(float), (hipStream_t)stream);
   hipLaunchKernelGGL(pool_bn_act_kernel, dim3(B, gy, nz), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scale, shift,
-                     (const bf16*)other, out, HW, C, act_silu, mul, rpz);
+                     (const bf16*)other, out, HW, C, act_silu, mul, rpz, (bf16*)act_out);
   return mmsim_check_launch("pool_bn_act");
+}
+
+extern "C" int mmsim_pool_bn_act(const void* z, const float* scale, const float* shift, const void* other, float* out, int B,
+                                 int HW, int C, int act_silu, float mul, void* stream) {
+  return pool_bn_act_impl(z, scale, shift, other, out, B, HW, C, act_silu, mul, nullptr, stream);
+}
+
+extern "C" int mmsim_pool_bn_act_store(const void* z, const float* scale, const float* shift, void* act_out, float* out, int B,
+                                       int HW, int C, float mul, void* stream) {
+  MMSIM_REQUIRE(act_out, "pool_bn_act_store: act_out required");
+  return pool_bn_act_impl(z, scale, shift, nullptr, out, B, HW, C, 1, mul, act_out, stream);
 }
 
 /* weT: scratch [RD][C] receiving conv_expand.weight transposed (reused by the backward of the same step) */

@@ -82,6 +82,16 @@ __device__ __forceinline__ void xform_tile(const GemmParams& p, int r0, int R, i
     if (!TRANS) { pix = r0 + (c >> 3); ch = k0 + (c & 7) * 8; ok = pix < R && ch < kend; if (pix >= R) pix = R - 1; if (ch >= kend) ch = k0; }
     else { pix = k0 + (c >> 4); ch = r0 + (c & 15) * 8; ok = pix < kend && ch < R; if (pix >= kend) pix = kend - 1; if (ch >= R) ch = r0; }
     const bf8 v = __builtin_bit_cast(bf8, reg[i]);
+    if (!p.xf_scale) {                   // launch-uniform: the operand is already activated, only the SE gate remains
+      const float* gp = p.xf_gate + (size_t)fdiv((unsigned int)pix, p.xf_dhw) * p.xf_C + ch;
+      const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      bf8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(v[e]) * g[e]);      // masked (zero) elements stay zero
+      reg[i] = __builtin_bit_cast(uint4, o);
+      continue;
+    }
     const float4 s0 = *reinterpret_cast<const float4*>(p.xf_scale + ch), s1 = *reinterpret_cast<const float4*>(p.xf_scale + ch + 4);
     const float4 h0 = *reinterpret_cast<const float4*>(p.xf_shift + ch), h1 = *reinterpret_cast<const float4*>(p.xf_shift + ch + 4);
     const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
@@ -315,7 +325,7 @@ extern "C" int mmsim_gemm_bf16_xf(int xf_operand, int M, int N, int K, const voi
                                   void* C, int ldc, int c_is_f32, const float* xf_scale, const float* xf_shift,
                                   const float* xf_gate, int xf_hw, int split_k, int accumulate, void* stream) {
   MMSIM_REQUIRE(xf_operand == 1 || xf_operand == 2, "gemm_xf: xf_operand must be 1 (A, forward) or 2 (B, wgrad)");
-  MMSIM_REQUIRE(xf_scale && xf_shift, "gemm_xf: scale/shift required");
+  MMSIM_REQUIRE((xf_scale && xf_shift) || (!xf_scale && !xf_shift && xf_gate), "gemm_xf: scale and shift, or neither with a gate (gate-only operand)");
   MMSIM_REQUIRE(((xf_operand == 1 ? K : N) % 8) == 0, "gemm_xf: transformed channel count must be a multiple of 8");
   return gemm_impl(xf_operand == 2, xf_operand == 1, M, N, K, A, lda, B, ldb, C, ldc, c_is_f32, nullptr, 0, nullptr, nullptr, 0,
                    1.0f, split_k, accumulate, xf_operand, xf_scale, xf_shift, xf_gate, xf_hw, stream);
@@ -329,7 +339,8 @@ extern "C" int mmsim_gemm_bf16_bnstats(int xf_operand, int M, int N, int K, cons
                                        void* C, int ldc, const float* xf_scale, const float* xf_shift, const float* xf_gate,
                                        int xf_hw, float* sums, float* scratch, unsigned long long scratch_floats, void* stream) {
   MMSIM_REQUIRE(xf_operand == 0 || xf_operand == 1, "gemm_bnstats: xf_operand must be 0 (plain) or 1 (transform A)");
-  MMSIM_REQUIRE(xf_operand == 0 || (xf_scale && xf_shift), "gemm_bnstats: scale/shift required with xf_operand 1");
+  MMSIM_REQUIRE(xf_operand == 0 || (xf_scale && xf_shift) || (!xf_scale && !xf_shift && xf_gate),
+                "gemm_bnstats: xf_operand 1 takes scale and shift, or neither with a gate (gate-only operand)");
   MMSIM_REQUIRE(sums && (N % 8) == 0, "gemm_bnstats: sums required, N must be a multiple of 8");
   const int tiles_m = (M + BM - 1) / BM;
   MMSIM_REQUIRE(scratch && (unsigned long long)tiles_m * 2 * N <= scratch_floats, "gemm_bnstats: scratch too small (need ceil(M/128)*2*N floats)");

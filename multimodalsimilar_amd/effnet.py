@@ -8,6 +8,7 @@ written once and never re-materialised activated.  Parameter names / shapes are 
 interchange; all parameters live in one flat buffer (fp32 master, fp32 grad, bf16 shadow).
 """
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -64,6 +65,10 @@ def count_macs(model_name, res=224):
         h = ho
     return macs + h * h * a.last * a.head
 
+
+# MMSIM_KEEP_A2=0: do not keep the activated depthwise output; the projection conv then applies BN + SiLU + gate while it
+# stages its operand (saves one [pixels, mid] bf16 tensor per block, costs ~2 ms/step at cfg4: those products become VALU-bound)
+_KEEP_A2 = os.environ.get("MMSIM_KEEP_A2", "1") != "0"
 
 class _Holder(nn.Module):
     pass
@@ -310,8 +315,14 @@ class EfficientNet(nn.Module):
         self._bn_finalize(st, n + "." + d_bn, sm, P_out)
         sc2, sh2 = self._bnp(st, n + "." + d_bn, 2), self._bnp(st, n + "." + d_bn, 3)
         bs.s = E(B, b.mid, dt=torch.float32)
-        lib.pool_bn_act(bs.z2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), None, bs.s.data_ptr(), B, Ho * Wo, b.mid, 1,
-                        1.0 / (Ho * Wo), s)
+        if _KEEP_A2:      # the SE squeeze also keeps a2 = silu(bn(z2)): the projection conv's operand is then a2 * gate
+            bs.a2 = E(P_out, b.mid)
+            lib.pool_bn_act_store(bs.z2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), bs.a2.data_ptr(), bs.s.data_ptr(), B, Ho * Wo,
+                                  b.mid, 1.0 / (Ho * Wo), s)
+        else:
+            bs.a2 = None
+            lib.pool_bn_act(bs.z2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), None, bs.s.data_ptr(), B, Ho * Wo, b.mid, 1,
+                            1.0 / (Ho * Wo), s)
         bs.hr = E(B, b.rd, dt=torch.float32)
         bs.hs = E(B, b.rd, dt=torch.float32)
         bs.gate = E(B, b.mid, dt=torch.float32)
@@ -323,8 +334,12 @@ class EfficientNet(nn.Module):
         bs.z3 = E(P_out, b.cout)
         w3 = SV(pw + ".weight", (b.cout, b.mid))
         sm = self._sums(st, n + "." + p_bn, "f")
-        lib.gemm_bf16_bnstats(1, P_out, b.cout, b.mid, bs.z2.data_ptr(), b.mid, w3.data_ptr(), b.mid, bs.z3.data_ptr(), b.cout,
-                              sc2.data_ptr(), sh2.data_ptr(), bs.gate.data_ptr(), Ho * Wo, sm.data_ptr(), *self._scr(), s)
+        if bs.a2 is not None:
+            lib.gemm_bf16_bnstats(1, P_out, b.cout, b.mid, bs.a2.data_ptr(), b.mid, w3.data_ptr(), b.mid, bs.z3.data_ptr(), b.cout,
+                                  None, None, bs.gate.data_ptr(), Ho * Wo, sm.data_ptr(), *self._scr(), s)
+        else:
+            lib.gemm_bf16_bnstats(1, P_out, b.cout, b.mid, bs.z2.data_ptr(), b.mid, w3.data_ptr(), b.mid, bs.z3.data_ptr(), b.cout,
+                                  sc2.data_ptr(), sh2.data_ptr(), bs.gate.data_ptr(), Ho * Wo, sm.data_ptr(), *self._scr(), s)
         self._bn_finalize(st, n + "." + p_bn, sm, P_out)
         nxt = E(P_out, b.cout)
         lib.bn_apply(bs.z3.data_ptr(), self._bnp(st, n + "." + p_bn, 2).data_ptr(), self._bnp(st, n + "." + p_bn, 3).data_ptr(),
@@ -413,9 +428,13 @@ class EfficientNet(nn.Module):
         self._bn_bwd(st, n + "." + p_bn, dx, bs.z3, P_out, b.cout, dz3, act=False)
         sc2, sh2 = self._bnp(st, n + "." + d_bn, 2), self._bnp(st, n + "." + d_bn, 3)
         gw3 = G(pw + ".weight").view(b.cout, b.mid)
-        lib.gemm_bf16_xf(2, b.cout, b.mid, P_out, dz3.data_ptr(), b.cout, bs.z2.data_ptr(), b.mid, gw3.data_ptr(), b.mid, 1,
-                         sc2.data_ptr(), sh2.data_ptr(), bs.gate.data_ptr(), Ho * Wo,
-                         ops.pick_split_k(b.cout, b.mid, P_out), 1, s)
+        if getattr(bs, "a2", None) is not None:
+            lib.gemm_bf16_xf(2, b.cout, b.mid, P_out, dz3.data_ptr(), b.cout, bs.a2.data_ptr(), b.mid, gw3.data_ptr(), b.mid, 1,
+                             None, None, bs.gate.data_ptr(), Ho * Wo, ops.pick_split_k(b.cout, b.mid, P_out), 1, s)
+        else:
+            lib.gemm_bf16_xf(2, b.cout, b.mid, P_out, dz3.data_ptr(), b.cout, bs.z2.data_ptr(), b.mid, gw3.data_ptr(), b.mid, 1,
+                             sc2.data_ptr(), sh2.data_ptr(), bs.gate.data_ptr(), Ho * Wo,
+                             ops.pick_split_k(b.cout, b.mid, P_out), 1, s)
         da2g = E(P_out, b.mid)
         ops.gemm(dz3, SV(pw + ".weight", (b.cout, b.mid)), da2g, b_kmajor=False)
         # one pass over (z2, da2g): dgate for the SE backward + the partial sums of the depthwise BN's backward statistics
