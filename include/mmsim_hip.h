@@ -33,7 +33,7 @@ const char* mmsim_last_error(void);
  * as called from transformer_emb.py:20-24), F.linear in arcface.py:47, timm 1x1 convs under
  * cv_classifier.py:49, nn.Linear cv_classifier.py:53 -- and autograd's dgrad / wgrad of each.
  * epilogue: 0 none | 1 GELU(erf): aux_out <- pre-activation, C <- gelu | 2 C <- acc * gelu'(aux_in)
- *           | 3 C <- acc + aux_in | 4 tanh.   split_k > 1 adds atomically into an f32 C (gradient buffers);
+ *           | 3 C <- acc + aux_in | 4 tanh | 5 row-fix (f32 C, see mmsim_arcface_rowfix; bias then holds [2][M] row vectors).   split_k > 1 adds atomically into an f32 C (gradient buffers);
  * accumulate != 0 makes C += result for split_k == 1 as well (f32 C only).
  * K-major operands must be zero in [K, round_up(K,8)) of each row when K % 8 != 0. */
 int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
@@ -120,6 +120,13 @@ int mmsim_arcface_ce(const float* cosm, int ld, const long long* label, float* l
 /* Backward of mmsim_arcface_margin for externally supplied dlogits (torch CrossEntropyLoss on the logits). */
 int mmsim_arcface_dlogits_to_dcos(const float* dlogits, int ld_dl, const float* cosm, int ld, const long long* label,
                                   void* dcos, int B, int C, float s, float m, int easy_margin, void* stream);
+
+/* Weight-gradient path of the head without the fp32 dW_hat round trip: rowvec [2][C] <- (inv_w[c], sum_b dcos[b][c] cos[b][c]);
+ * mmsim_gemm_bf16 with epilogue 5 (row-fix: C[m][n] (+)= bias[m] * (acc - aux_in[m][n] * bias[M + m]), bias = rowvec,
+ * aux_in = W_hat bf16) then writes dW = (dW_hat - w_hat (w_hat . dW_hat)) / ||w|| straight into the gradient buffer: the
+ * backward of F.normalize(self.weight) (arcface.py:47) folded into dcos^T x_hat. */
+int mmsim_arcface_rowfix(const void* dcos, const float* cosm, int ld, const float* inv_w, float* rowvec, int B, int C,
+                         void* stream);
 
 /* ---- small glue ------------------------------------------------------------------------------- */
 int mmsim_cast_f32_to_bf16(const float* x, void* y, unsigned long long n, void* stream);

@@ -224,9 +224,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     }
     if (!p.c_f32) fast_epilogue_epi<0, true>(p, acc, row0, col0, lane, fs, stg);
     else if (p.atomic) fast_epilogue<EPI_NONE, 3, true>(p, acc, row0, col0, lane, fs, stg);
+    else if (p.accum && p.epi == EPI_ROWFIX) fast_epilogue<EPI_ROWFIX, 2, true>(p, acc, row0, col0, lane, fs, stg);
     else if (p.accum) fast_epilogue<EPI_NONE, 2, true>(p, acc, row0, col0, lane, fs, stg);
     else if (p.epi == EPI_TANH) fast_epilogue<EPI_TANH, 1, true>(p, acc, row0, col0, lane, fs, stg);
     else if (p.epi == EPI_NONE) fast_epilogue<EPI_NONE, 1, true>(p, acc, row0, col0, lane, fs, stg);
+    else if (p.epi == EPI_ROWFIX) fast_epilogue<EPI_ROWFIX, 1, true>(p, acc, row0, col0, lane, fs, stg);
     else gemm_epilogue(p, acc, row0, col0, lane, fs);          // f32 output with a fused epilogue: direct form
   }
 }
@@ -252,13 +254,16 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   MMSIM_REQUIRE((ldc % 4) == 0, "gemm: ldc must be a multiple of 4");
   MMSIM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
                 "gemm: operands must be 16-byte aligned");
-  MMSIM_REQUIRE(epilogue >= 0 && epilogue <= 4, "gemm: unknown epilogue");
+  MMSIM_REQUIRE(epilogue >= 0 && epilogue <= 5, "gemm: unknown epilogue");
+  MMSIM_REQUIRE(epilogue != EPI_ROWFIX || (c_is_f32 && split_k == 1 && bias && aux_in),
+                "gemm: the row-fix epilogue needs an f32 output, no split-K, the [2][M] row vectors in bias and aux_in");
   MMSIM_REQUIRE(!(epilogue == EPI_GELU) || aux_out, "gemm: GELU epilogue needs aux_out (pre-activation)");
   MMSIM_REQUIRE(!(epilogue == EPI_MUL_GELU_GRAD || epilogue == EPI_ADD) || aux_in, "gemm: epilogue needs aux_in");
   MMSIM_REQUIRE(epilogue == EPI_NONE || (ld_aux % 4) == 0 || epilogue == EPI_TANH, "gemm: ld_aux must be a multiple of 4");
   MMSIM_REQUIRE(split_k >= 1, "gemm: split_k >= 1");
   MMSIM_REQUIRE(split_k == 1 || (c_is_f32 && epilogue == EPI_NONE), "gemm: split-K needs f32 output and no epilogue");
   MMSIM_REQUIRE(!accumulate || c_is_f32, "gemm: accumulate needs f32 output");
+  MMSIM_REQUIRE(!accumulate || epilogue == EPI_NONE || epilogue == EPI_ROWFIX, "gemm: accumulate with this epilogue is not implemented");
   // leading dimensions must cover the extents rounded up to the 8-element load granule
   const int a_cols = trans_a ? M : K, b_cols = b_kmajor ? K : N;
   MMSIM_REQUIRE(lda >= ((a_cols + 7) & ~7) && ldb >= ((b_cols + 7) & ~7), "gemm: leading dimension too small");

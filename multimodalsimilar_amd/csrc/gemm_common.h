@@ -14,7 +14,9 @@ struct GemmParams {
   int dbg;   // ablation switches for tools/bench_gemm.py (MMSIM_GEMM_DBG): 1 no DMA, 2 no LDS reads, 4 no MFMA; 0 in production
 };
 
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_MUL_GELU_GRAD = 2, EPI_ADD = 3, EPI_TANH = 4 };
+// EPI_ROWFIX: C[m][n] (+)= r[m] * (acc - aux_in[m][n] * r[M + m]) with the two fp32 row vectors r passed in `bias` ([2][M]):
+// the backward of a row L2-normalisation folded into the product that feeds it (ArcFace weight gradient, head.py).
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_MUL_GELU_GRAD = 2, EPI_ADD = 3, EPI_TANH = 4, EPI_ROWFIX = 5 };
 
 // Epilogue for full tiles, staged through LDS so that every global access is row-contiguous: the wave's 64x64
 // fp32 tile is written to its private LDS region (the operand ring is free by then) and read back one row segment
@@ -39,7 +41,7 @@ __device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][
     return;
   }
   const int c4 = (lane & 15) * 4, n = col0 + c4;
-  const bool add_bias = (p.bias != nullptr) && first_split;
+  const bool add_bias = (p.bias != nullptr) && first_split && EPI != EPI_ROWFIX;
   float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
   if (add_bias) {
     if (!CHECK || n + 3 < p.N) bias = *reinterpret_cast<const float4*>(p.bias + n);
@@ -56,6 +58,7 @@ __device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][
         if (EPI == EPI_GELU) { const bf16 pre = f2bf(v); p.aux_out[m * p.ld_aux + n + e] = pre; v = gelu_f(bf2f(pre)); }
         else if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_grad_f(bf2f(p.aux_in[m * p.ld_aux + n + e]));
         else if (EPI == EPI_ADD) v += bf2f(p.aux_in[m * p.ld_aux + n + e]);
+        else if (EPI == EPI_ROWFIX) v = p.bias[m] * (v - bf2f(p.aux_in[m * p.ld_aux + n + e]) * p.bias[(size_t)p.M + m]);
         else if (EPI == EPI_TANH) v = tanhf(v);
         if (CMODE == 0) reinterpret_cast<bf16*>(p.C)[m * p.ldc + n + e] = f2bf(v);
         else if (CMODE == 1) reinterpret_cast<float*>(p.C)[m * p.ldc + n + e] = v;
@@ -87,6 +90,11 @@ __device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][
     } else if (EPI == EPI_TANH) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+    } else if (EPI == EPI_ROWFIX) {
+      const bf4 x = *reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n);
+      const float rs = p.bias[m], rr = p.bias[(size_t)p.M + m];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rs * (v[e] - bf2f(x[e]) * rr);
     }
     if (CMODE == 0) {
       bf4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};

@@ -249,6 +249,34 @@ extern "C" int mmsim_arcface_dlogits_to_dcos(const float* dlogits, int ld_dl, co
   return mmsim_check_launch("dlogits_to_dcos");
 }
 
+// rowvec[c] = inv_w[c], rowvec[C + c] = sum_b dcos[b][c] * cos[b][c]  ( = w_hat_c . dW_hat_c, because cos = x_hat W_hat^T and
+// dW_hat = dcos^T x_hat): the two row vectors of the GEMM's row-fix epilogue, from one pass over the [B, C] matrices.
+__global__ __launch_bounds__(256) void arcface_rowfix_kernel(const bf16* __restrict__ dcos, const float* __restrict__ cosm, int ld,
+                                                             const float* __restrict__ inv_w, float* __restrict__ rowvec, int B, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int b = 0;
+  for (; b + 4 <= B; b += 4) {            // four independent row loads in flight per lane
+    const size_t o = (size_t)b * ld + c;
+    a0 += bf2f(dcos[o]) * cosm[o];
+    a1 += bf2f(dcos[o + ld]) * cosm[o + ld];
+    a2 += bf2f(dcos[o + 2 * (size_t)ld]) * cosm[o + 2 * (size_t)ld];
+    a3 += bf2f(dcos[o + 3 * (size_t)ld]) * cosm[o + 3 * (size_t)ld];
+  }
+  for (; b < B; ++b) a0 += bf2f(dcos[(size_t)b * ld + c]) * cosm[(size_t)b * ld + c];
+  rowvec[c] = inv_w[c];
+  rowvec[(size_t)C + c] = (a0 + a1) + (a2 + a3);
+}
+
+extern "C" int mmsim_arcface_rowfix(const void* dcos, const float* cosm, int ld, const float* inv_w, float* rowvec, int B, int C,
+                                    void* stream) {
+  MMSIM_REQUIRE(dcos && cosm && inv_w && rowvec && B > 0 && C > 0 && ld >= C, "arcface_rowfix: bad arguments");
+  hipLaunchKernelGGL(arcface_rowfix_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)dcos, cosm, ld,
+                     inv_w, rowvec, B, C);
+  return mmsim_check_launch("arcface_rowfix");
+}
+
 static int grid_for(size_t n, int per_block) {
   size_t g = (n + per_block - 1) / per_block;
   if (g > 8192) g = 8192;

@@ -6,6 +6,7 @@ normalise -> bf16 MFMA cosine GEMM -> margin + scaled cross-entropy + argmax + d
 cosines (no logits / softmax / one-hot tensors), then the two backward GEMMs and the normalise backward.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -13,6 +14,10 @@ import torch.nn as nn
 from . import ops
 from .flat import FlatBuffer
 from ._lib import MmsimError
+
+
+# MMSIM_HEAD_FUSED_DW=0: weight gradient through an fp32 dW_hat buffer + a separate normalise-backward pass (A/B switch)
+_FUSED_DW = os.environ.get("MMSIM_HEAD_FUSED_DW", "1") != "0"
 
 
 def _margin_consts(m):
@@ -96,21 +101,29 @@ class ArcMarginProduct(nn.Module):
         ops.gemm(xh, wh, cos[:, :C])                                                 # F.linear  (arcface.py:47)
         return cos, dict(x=x, xh=xh, wh=wh, inv_x=inv_x, inv_w=inv_w, B=B, ldc=ldc)
 
-    def _backward_from_dcos(self, st, dcos):
-        """dcos bf16 [B, ldc] (pad zero) -> dx f32 [B,D]; accumulates into weight.grad."""
+    def _backward_from_dcos(self, st, dcos, cos=None):
+        """dcos bf16 [B, ldc] (pad zero) -> dx f32 [B,D]; accumulates into weight.grad.  With the cosines at hand the backward of
+        F.normalize(self.weight) is folded into the dcos^T x_hat product's epilogue (no fp32 dW_hat round trip, no second pass
+        over W): w_hat . dW_hat = sum_b dcos cos, so both row vectors of the correction are known before the product runs."""
         B, D, C, ldc = st["B"], self.in_feature, self.out_feature, st["ldc"]
         self._bind_grads()
         dxh = self._buf("dxh", (B, D), torch.float32)
-        dwh = self._buf("dwh", (C, D), torch.float32)
         dx = torch.empty((B, D), dtype=torch.float32, device=dcos.device)
         # dxh = dcos @ Wh: 2 x 22 output tiles over a 100k-long reduction -> split-K (fp32 atomics into the zeroed buffer)
         sk = ops.pick_split_k(B, D, C)
         if sk > 1:
             dxh.zero_()
         ops.gemm(dcos[:, :C], st["wh"], dxh, b_kmajor=False, split_k=sk, accumulate=sk > 1)
-        ops.gemm(dcos[:, :C], st["xh"], dwh, trans_a=True, b_kmajor=False)           # dWh = dcos^T @ xh
         ops.l2norm_bwd(st["x"], st["inv_x"], dxh, 0, dx)
-        ops.l2norm_bwd(self.weight.detach(), st["inv_w"], dwh, 0, self._flat.gview("weight"), accumulate=True)
+        if cos is not None and _FUSED_DW:
+            rowvec = self._buf("rowvec", (2, C), torch.float32)
+            ops.lib.arcface_rowfix(dcos.data_ptr(), cos.data_ptr(), ldc, st["inv_w"].data_ptr(), rowvec.data_ptr(), B, C, ops._stream())
+            ops.gemm(dcos[:, :C], st["xh"], self._flat.gview("weight").view(C, D), trans_a=True, b_kmajor=False, bias=rowvec,
+                     epilogue=ops.EPI_ROWFIX, aux_in=st["wh"], accumulate=True)
+        else:
+            dwh = self._buf("dwh", (C, D), torch.float32)
+            ops.gemm(dcos[:, :C], st["xh"], dwh, trans_a=True, b_kmajor=False)           # dWh = dcos^T @ xh
+            ops.l2norm_bwd(self.weight.detach(), st["inv_w"], dwh, 0, self._flat.gview("weight"), accumulate=True)
         if self.grad_ready_hook:
             self.grad_ready_hook(self._flat, 0, self._flat.total)
         return dx
@@ -162,7 +175,7 @@ class _ArcLogitsFn(torch.autograd.Function):
         ops.lib.arcface_dlogits_to_dcos(dlogits.data_ptr(), dlogits.stride(0), ctx.cos.data_ptr(), st["ldc"],
                                         ctx.label.data_ptr(), dcos.data_ptr(), st["B"], C, mod.s, mod.m,
                                         int(mod.easy_margin), ops._stream())
-        dx = mod._backward_from_dcos(st, dcos)
+        dx = mod._backward_from_dcos(st, dcos, ctx.cos)
         return dx, None, None, None
 
 
@@ -179,7 +192,7 @@ class _ArcLossFn(torch.autograd.Function):
         ops.lib.arcface_ce(cos.data_ptr(), st["ldc"], label.data_ptr(), loss_b.data_ptr(), argmax.data_ptr(),
                            None if dcos is None else dcos.data_ptr(), B, C, mod.s, mod.m, int(mod.easy_margin),
                            1.0 / B, mod._err_flag().data_ptr(), ops._stream())
-        ctx.mod, ctx.st, ctx.dcos = mod, st, dcos
+        ctx.mod, ctx.st, ctx.dcos, ctx.cos = mod, st, dcos, cos       # cos: the module's scratch, intact until the next forward
         ctx.mark_non_differentiable(argmax)
         return loss_b.mean(), argmax
 
@@ -187,7 +200,7 @@ class _ArcLossFn(torch.autograd.Function):
     def backward(ctx, dloss, _dargmax):
         dcos = ctx.dcos
         dcos.mul_(dloss.to(dcos.dtype))      # chain rule for a non-unit upstream gradient (bf16(1.0) is exact)
-        dx = ctx.mod._backward_from_dcos(ctx.st, dcos)
+        dx = ctx.mod._backward_from_dcos(ctx.st, dcos, ctx.cos)
         return dx, None, None, None
 
 

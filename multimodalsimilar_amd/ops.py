@@ -14,7 +14,7 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 I64 = torch.int64
 
-EPI_NONE, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_ADD, EPI_TANH = 0, 1, 2, 3, 4
+EPI_NONE, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_ADD, EPI_TANH, EPI_ROWFIX = 0, 1, 2, 3, 4, 5
 
 
 def _stream():
@@ -104,9 +104,9 @@ def gemm(a, b, c, *, trans_a=False, b_kmajor=True, bias=None, epilogue=EPI_NONE,
         raise ValueError(f"gemm: shape mismatch a{tuple(a.shape)} b{tuple(b.shape)} c{tuple(c.shape)} "
                          f"trans_a={trans_a} b_kmajor={b_kmajor}")
     if bias is not None:
-        _chk(bias, F32, "gemm.bias", 1)
-        if bias.shape[0] != N:
-            raise ValueError("gemm.bias: length must equal N")
+        _chk(bias, F32, "gemm.bias")
+        if bias.numel() != (2 * M if epilogue == EPI_ROWFIX else N):
+            raise ValueError("gemm.bias: length must equal N (2*M row vectors for the row-fix epilogue)")
     ld_aux = 0
     for t, nm in ((aux_in, "gemm.aux_in"), (aux_out, "gemm.aux_out")):
         if t is not None:
@@ -129,6 +129,11 @@ def pick_split_k(M, N, K):
         t, s = (M // 256) * (N // 256), 1
         while t * s < 192 and K // (s * 2) >= 512:
             s *= 2
+        # any split count works (the K range is cut in multiples of 64): take the largest one that still fits the same
+        # number of 256-CU rounds -- 48 tiles (the q|k|v weight gradient) run as 5 x 48 = 240 blocks instead of 4 x 48 = 192
+        rounds = -(-(t * s) // 256)
+        while (t * (s + 1)) <= rounds * 256 and K // (s + 1) >= 512 and os.environ.get("MMSIM_SPLITK_EXACT", "1") != "0":
+            s += 1
         return s * mult
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     s = 1

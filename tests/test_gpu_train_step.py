@@ -73,7 +73,10 @@ def test_two_tower_step_literal_and_fused_paths_agree_and_track_oracle():
     ref = [orc.step(T.synthetic_batch(cfg, "cpu", seed=70 + i))[0].item() for i in range(3)]
     print("\nfused", losses[True], "\nliteral", losses[False], "\noracle", ref)
     for a, b in zip(losses[True], losses[False]):
-        assert abs(a - b) < 2e-3 * abs(b)          # same kernels underneath, only the loss plumbing differs
+        # same kernels underneath, only the loss plumbing differs.  Not bit-equal run to run: split-K weight gradients add
+        # with fp32 atomics, and AdamW's first updates are ~lr * sign(g), so an element whose gradient is ~0 may flip; the
+        # second / third losses were observed to take values 0.2 % apart between identical runs (44.048 / 43.952, 44.569 / 44.540)
+        assert abs(a - b) < 5e-3 * abs(b)
     for a, b in zip(losses[True], ref):
         assert abs(a - b) < 3e-2 * abs(b)
 
