@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--literal-loss", action="store_true", help="materialised logits + nn.CrossEntropyLoss instead of the fused head")
     args = ap.parse_args()
 
+    # before the first HIP call of the process: the host driver only supports dmabuf IPC (RCCL / cross-process tensors)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -354,3 +354,37 @@ def test_pointwise_conv_with_bn_statistics(P, Cin, Cout, xf):
     ssum, ssq = zf.double().sum(0), (zf.double() ** 2).sum(0)
     assert (sums[:Cout].double() - ssum).abs().max() < 1e-4 * zf.abs().double().sum(0).max() + 1e-3      # fp32 summation order
     assert (sums[Cout:].double() - ssq).abs().max() < 1e-4 * ssq.max() + 1e-3
+
+
+def test_squeeze_that_keeps_the_activation_and_gate_only_operand():
+    """mmsim_pool_bn_act_store (SE squeeze + a2 = silu(bn(z2)) kept) and the gate-only operand transform of the projection
+    conv (forward and weight gradient) against the recompute form and fp32 torch."""
+    lib, s = _lib()
+    B, HW, Cin, Cout = 6, 49, 144, 40
+    P = B * HW
+    z2 = rnd(P, Cin, seed=4).bfloat16()
+    scale, shift = 1 + 0.1 * rnd(Cin, seed=5), 0.1 * rnd(Cin, seed=6)
+    a_ref = F.silu(z2.float() * scale + shift)
+    a2 = torch.empty(P, Cin, dtype=torch.bfloat16, device=DEV)
+    sq = torch.empty(B, Cin, device=DEV)
+    lib.pool_bn_act_store(z2.data_ptr(), scale.data_ptr(), shift.data_ptr(), a2.data_ptr(), sq.data_ptr(), B, HW, Cin, 1.0 / HW, s)
+    assert relerr(a2, a_ref) < 1e-2
+    assert relerr(sq, a_ref.view(B, HW, Cin).mean(1)) < 1e-3
+    sq2 = torch.empty(B, Cin, device=DEV)
+    lib.pool_bn_act(z2.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, sq2.data_ptr(), B, HW, Cin, 1, 1.0 / HW, s)
+    assert torch.equal(sq, sq2)                      # the pooled value does not depend on whether a2 is kept
+    gate = torch.sigmoid(rnd(B, Cin, seed=7))
+    w3 = rnd(Cout, Cin, seed=8, scale=0.2).bfloat16()
+    ag = (a2.float().view(B, HW, Cin) * gate.unsqueeze(1)).reshape(P, Cin)
+    out = torch.empty(P, Cout, dtype=torch.bfloat16, device=DEV)
+    lib.gemm_bf16_xf(1, P, Cout, Cin, a2.data_ptr(), Cin, w3.data_ptr(), Cin, out.data_ptr(), Cout, 0, None, None, gate.data_ptr(),
+                     HW, 1, 0, s)
+    assert relerr(out, ag @ w3.float().t()) < 1.5e-2
+    dz3 = rnd(P, Cout, seed=9).bfloat16()
+    gw = torch.zeros(Cout, Cin, device=DEV)
+    lib.gemm_bf16_xf(2, Cout, Cin, P, dz3.data_ptr(), Cout, a2.data_ptr(), Cin, gw.data_ptr(), Cin, 1, None, None, gate.data_ptr(),
+                     HW, 2, 1, s)
+    assert relerr(gw, dz3.float().t() @ ag) < 1.5e-2
+    from multimodalsimilar_amd._lib import MmsimError
+    with pytest.raises(MmsimError):                  # neither scale/shift nor a gate: rejected before launch
+        lib.gemm_bf16_xf(1, P, Cout, Cin, a2.data_ptr(), Cin, w3.data_ptr(), Cin, out.data_ptr(), Cout, 0, None, None, None, HW, 1, 0, s)

@@ -269,3 +269,31 @@ def test_adamw_matches_golden(golden_dir):
             ref = torch.from_numpy(d[f"p{t + 1}_{j}"]).flatten().to(DEV)
             assert torch.allclose(p[offs[j]:offs[j] + sizes[j]], ref, rtol=2e-5, atol=1e-6)
     assert torch.equal(sh, p.bfloat16())
+
+
+@pytest.mark.parametrize("C,D,B", [(96, 1408, 8), (1000, 520, 24), (333, 72, 256)])
+def test_head_weight_gradient_rowfix_epilogue(C, D, B):
+    """The ArcFace weight gradient through the row-fix epilogue (mmsim_arcface_rowfix + mmsim_gemm_bf16 epilogue 5) against
+    autograd through F.normalize(weight) (arcface.py:47) on the same bf16-rounded operands, accumulating into a non-zero buffer."""
+    ops = _ops()
+    w = rnd(C, D, scale=0.3, seed=1).requires_grad_(True)
+    xh = F.normalize(rnd(B, D, seed=2)).bfloat16()
+    dcos = rnd(B, C, scale=0.05, seed=3).bfloat16()
+    wh_f = F.normalize(w)                                   # fp32; the kernels see its bf16 rounding
+    wh = wh_f.detach().bfloat16()
+    cos = (xh.float() @ wh.float().t()).contiguous()        # what the forward product returns
+    ((xh.float() @ wh_f.t()) * dcos.float()).sum().backward()
+    inv_w = (1.0 / w.detach().norm(dim=1)).contiguous()
+    ldc = ops.round_up(C, 8)
+    dcos_p = torch.zeros(B, ldc, dtype=torch.bfloat16, device=DEV); dcos_p[:, :C] = dcos
+    cos_p = torch.zeros(B, ldc, device=DEV); cos_p[:, :C] = cos
+    rowvec = torch.empty(2, C, device=DEV)
+    ops.lib.arcface_rowfix(dcos_p.data_ptr(), cos_p.data_ptr(), ldc, inv_w.data_ptr(), rowvec.data_ptr(), B, C, ops._stream())
+    assert relerr(rowvec[0], inv_w) == 0.0
+    assert relerr(rowvec[1], (dcos.float() * cos).sum(0)) < 1e-5
+    prev = rnd(C, D, scale=0.01, seed=4)
+    out = prev.clone()
+    ops.gemm(dcos_p[:, :C], xh, out, trans_a=True, b_kmajor=False, bias=rowvec, epilogue=ops.EPI_ROWFIX, aux_in=wh, accumulate=True)
+    assert relerr(out - prev, w.grad) < 1e-2               # w_hat enters the correction bf16-rounded: 2^-9-class differences
+    with pytest.raises(Exception):
+        ops.gemm(dcos_p[:, :C], xh, out.bfloat16(), trans_a=True, b_kmajor=False, bias=rowvec, epilogue=ops.EPI_ROWFIX, aux_in=wh)
