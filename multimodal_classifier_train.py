@@ -22,20 +22,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from multimodalsimilar_amd import train as T  # noqa: E402
 
-remove_words = ['【福利秒杀】', '【每日福利】', '【福利爆款】', '【专柜品质】', '【1元秒杀】', '【直播专用1元秒杀】', '【', '】', '源本']
-
-
-def preprocess_for_infer(spu_names):
-    """Title cleaning of the reference (multimodal_dataset.py:21-31): drop promo tags and [...] spans."""
-    import re
-    out = []
-    for line in spu_names:
-        for r in remove_words:
-            line = line.replace(r, '')
-        for c in re.findall(r'\[[^()]*\]', line):
-            line = line.replace(c, '')
-        out.append(line)
-    return out
+from multimodalsimilar_amd.data import MultimodalDataset, collate_fn, finish_batch, preprocess_for_infer, remove_words  # noqa: E402,F401
 
 
 class RunningAccuracy:
@@ -73,6 +60,11 @@ def main(argv=None):
     ap.add_argument("--save-dir", default=None, help="directory for {step}.pt whole-module checkpoints (reference :227)")
     ap.add_argument("--literal-loss", action="store_true", help="materialised logits + nn.CrossEntropyLoss (the reference's literal path)")
     ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--train-csv", default=None, help="csv with spu_sn, spu_name, cateid columns (reference :128-133)")
+    ap.add_argument("--test-csv", default=None)
+    ap.add_argument("--img-dir", default=None, help="directory holding {spu_sn}.jpg")
+    ap.add_argument("--vocab", default=None, help="local BERT vocab.txt (the reference fetches hfl/chinese-roberta-wwm-ext by name)")
+    ap.add_argument("--num-workers", type=int, default=16)                # reference :141
     ap.add_argument("--log-every", type=int, default=10)
     ap.add_argument("--max-steps", type=int, default=None)
     args = ap.parse_args(argv)
@@ -97,6 +89,25 @@ def main(argv=None):
     else:
         model = T.build_model(cfg, device, seed=0)
 
+    loaders = None
+    if args.train_csv and not args.synthetic:
+        if not (args.img_dir and args.vocab):
+            raise SystemExit("--train-csv needs --img-dir and --vocab (a local vocab.txt; nothing can be downloaded)")
+        from torch.utils.data import DataLoader, DistributedSampler
+        from multimodalsimilar_amd.data import load_tokenizer
+        from multimodalsimilar_amd.preprocess import create_transform
+        tokenizer = load_tokenizer(args.vocab)
+        transform_eff = create_transform(input_size=(3, args.res, args.res), interpolation="bicubic", crop_pct=1.0, device=device)
+        def make(csv, shuffle):
+            ds = MultimodalDataset(tokenizer=tokenizer, transform=transform_eff, csv_path=csv, img_path=args.img_dir,
+                                   use_label=True, max_length=args.seq_len)
+            sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=shuffle) if world > 1 else None
+            return DataLoader(ds, shuffle=shuffle and sampler is None, sampler=sampler, batch_size=args.batch_size,
+                              collate_fn=collate_fn, num_workers=args.num_workers, drop_last=True)
+        loaders = (make(args.train_csv, True), make(args.test_csv, False) if args.test_csv else None)
+        args.steps_per_epoch = len(loaders[0])
+        if tokenizer.vocab_size > model.nlp.ptm.config.vocab_size:
+            raise SystemExit(f"vocab.txt has {tokenizer.vocab_size} entries, the text tower's embedding table {model.nlp.ptm.config.vocab_size}")
     num_training_steps = args.num_epochs * args.steps_per_epoch          # reference :150
     step = T.TrainStep(model, "multimodal", num_training_steps, fused_loss=not args.literal_loss)
     train_accuracy, test_accuracy = RunningAccuracy(device), RunningAccuracy(device)
@@ -109,8 +120,14 @@ def main(argv=None):
 
     global_step, test_acc, t_last = 0, 0.0, time.time()
     for epoch in range(args.num_epochs):
+        data_iter = iter(loaders[0]) if loaders else None
+        if loaders and world > 1:
+            loaders[0].sampler.set_epoch(epoch)
         for it in range(args.steps_per_epoch):
-            batch = T.synthetic_batch(cfg, device, seed=1234 + rank + 1000003 * global_step)
+            if data_iter is not None:
+                batch = finish_batch(next(data_iter), transform_eff, device)
+            else:
+                batch = T.synthetic_batch(cfg, device, seed=1234 + rank + 1000003 * global_step)
             loss, pred = step.step(batch)                                 # :179-201
             train_accuracy(pred, batch["labels"])                        # :191-192
             global_step += 1
@@ -127,8 +144,9 @@ def main(argv=None):
                 t_last = time.time()
             if global_step % args.eval_every == 0:                        # :210-225
                 model.eval()
-                for eb in range(args.eval_batches):
-                    tb = T.synthetic_batch(cfg, device, seed=99 + eb)
+                test_iter = iter(loaders[1]) if loaders and loaders[1] is not None else None
+                for eb in range(args.eval_batches if test_iter is None else min(args.eval_batches, len(loaders[1]))):
+                    tb = finish_batch(next(test_iter), transform_eff, device) if test_iter is not None else T.synthetic_batch(cfg, device, seed=99 + eb)
                     with torch.no_grad():
                         cos = model(**{**T.model_inputs("multimodal", tb), "is_test": True})
                     test_accuracy(torch.argmax(cos, dim=-1), tb["labels"])

@@ -194,3 +194,26 @@ def test_ragged_batch_sizes_train_and_eval(B):
     assert e1.shape == (B, model.emb_size) and torch.equal(e1, e2) and torch.isfinite(e1).all()
     assert torch.allclose(e1.norm(dim=1), torch.full((B,), 2.0 ** 0.5, device="cuda"), atol=1e-3)      # two unit halves (:54-56)
     assert logits.shape == (B, cfg["classes"]) and logits.abs().max() <= 1.0 + 1e-3                   # cosines (arcface.py:65-67)
+
+
+def test_entry_point_trains_on_the_reference_data_format(tmp_path):
+    """multimodal_classifier_train.main on a csv + jpg directory + local vocab.txt in the reference's format
+    (multimodal_dataset.py:36-64): DataLoader workers decode / tokenise, the GPU input stage builds img_tensor, two
+    training steps and one eval pass run, the loss is finite and the image batch equals the Pillow-pinned oracle's."""
+    import numpy as np
+    from test_data_host import make_dataset
+    import multimodal_classifier_train as entry
+    from multimodalsimilar_amd import data as D
+    from multimodalsimilar_amd.preprocess import create_transform
+    from oracle import preprocess_ref as P
+    csv, img_dir, vocab = make_dataset(str(tmp_path), n=9)
+    model = entry.main(["--train-csv", csv, "--test-csv", csv, "--img-dir", img_dir, "--vocab", vocab, "--text-model", "tiny",
+                        "--image-model", "efficientnet_b0", "--res", "64", "--seq-len", "32", "--batch-size", "4", "--num-labels", "3",
+                        "--num-epochs", "1", "--num-workers", "2", "--eval-every", "2", "--eval-batches", "1", "--log-every", "1",
+                        "--max-steps", "2"])
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    ds = D.MultimodalDataset(D.load_tokenizer(vocab), None, csv, img_dir, use_label=True, max_length=32)
+    tf = create_transform(input_size=(3, 64, 64), interpolation="bicubic", crop_pct=1.0)
+    batch = D.finish_batch(D.collate_fn([ds[0], ds[5]]), tf, DEV)
+    assert batch["img_tensor"].shape == (2, 3, 64, 64) and batch["input_ids"].shape == (2, 32) and batch["labels"].tolist() == [0, 2]
+    assert np.array_equal(batch["img_tensor"][1].cpu().numpy(), P.eval_transform(ds[5][0], 64, 1.0))
