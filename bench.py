@@ -195,6 +195,9 @@ def main():
     batch = train.synthetic_batch(cfg, device, seed=1234 + rank, ragged_masks=args.ragged_masks)
     timer = GemmTimer(ops)
     timer.install()
+    if os.environ.get("MMSIM_MAIN_PRIORITY"):      # experiment: the caller's (text tower's) stream at another HIP priority
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=int(os.environ["MMSIM_MAIN_PRIORITY"])))
 
     for _ in range(args.warmup):
         loss, _ = step.step(batch)
