@@ -219,6 +219,13 @@ int mmsim_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_sh
                      float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                      void* stream);
 
+/* The same update for a row-normalised weight matrix p [R][D] (the ArcFace head), one wave per row, which also leaves
+ * w_hat bf16 [R][D] = p / max(||p_row||, l2_eps) and inv_norm [R] for the NEXT forward: F.normalize(self.weight) (arcface.py:47)
+ * then needs no pass of its own.  D % 4 == 0, D <= 4096. */
+int mmsim_adamw_rows_l2norm(float* p, const float* g, float* m, float* v, void* w_hat, float* inv_norm, int R, int D,
+                            float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                            float l2_eps, void* stream);
+
 /* ---- exhaustive inner-product top-k search (nlp_infer.py:139-152, daodian_infer.py:225-230, 295-302:
  * faiss.normalize_L2 + IndexFlat(METRIC_INNER_PRODUCT).add / .search) ------------------------------------------------
  * mmsim_split_bf16_cat: x fp32 [R, D] (* scale) -> bf16 [R, 3D]: [hi | lo | hi] for queries (db_side 0), [hi | hi | lo] for the

@@ -207,6 +207,59 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
   }
 }
 
+// AdamW for a row-normalised weight matrix (the ArcFace head): one wave per row does the same update as adamw_kernel and,
+// with the updated row still in registers, leaves w_hat = w / max(||w||, eps) in bf16 and 1 / max(||w||, eps) for the NEXT
+// forward -- F.normalize(self.weight) (arcface.py:47) costs no pass of its own (it was a 1.1 GB read + 0.56 GB write per step at
+// 100 000 x 2816), and the bf16 shadow copy the plain kernel writes (unused by the head) is not written.
+template <int MAXC>
+__global__ __launch_bounds__(256) void adamw_rows_l2norm_kernel(float* p, const float* g, float* m, float* v, bf16* wh, float* inv_norm,
+                                                                int R, int D, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                                float rsqrt_bc2, float gscale, float l2eps) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= R) return;
+  typedef float __attribute__((ext_vector_type(4))) fv4;
+  float P[MAXC][4];
+  float ss = 0.f;
+  const size_t base = (size_t)row * D;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int col = lane * 4 + c * 256;
+    if (col < D) {
+      const size_t i = base + col;
+      const float4 pg = *reinterpret_cast<const float4*>(g + i);
+      const float4 pp = *reinterpret_cast<const float4*>(p + i), pm = *reinterpret_cast<const float4*>(m + i),
+                   pv = *reinterpret_cast<const float4*>(v + i);
+      float G[4] = {pg.x, pg.y, pg.z, pg.w}, Mm[4] = {pm.x, pm.y, pm.z, pm.w}, V[4] = {pv.x, pv.y, pv.z, pv.w};
+      P[c][0] = pp.x; P[c][1] = pp.y; P[c][2] = pp.z; P[c][3] = pp.w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gg = G[e] * gscale;
+        P[c][e] *= (1.0f - lr * wd);
+        Mm[e] = b1 * Mm[e] + (1.0f - b1) * gg;
+        V[e] = b2 * V[e] + (1.0f - b2) * gg * gg;
+        const float denom = sqrtf(V[e]) * rsqrt_bc2 + eps;
+        P[c][e] -= (lr / bc1) * (Mm[e] / denom);
+        ss += P[c][e] * P[c][e];
+      }
+      __builtin_nontemporal_store((fv4){P[c][0], P[c][1], P[c][2], P[c][3]}, reinterpret_cast<fv4*>(p + i));
+      __builtin_nontemporal_store((fv4){Mm[0], Mm[1], Mm[2], Mm[3]}, reinterpret_cast<fv4*>(m + i));
+      __builtin_nontemporal_store((fv4){V[0], V[1], V[2], V[3]}, reinterpret_cast<fv4*>(v + i));
+    }
+  }
+  ss = wave_sum(ss);
+  const float inv = 1.0f / fmaxf(sqrtf(ss), l2eps);
+  if (lane == 0) inv_norm[row] = inv;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int col = lane * 4 + c * 256;
+    if (col < D) {
+      const bf4 o = {f2bf(P[c][0] * inv), f2bf(P[c][1] * inv), f2bf(P[c][2] * inv), f2bf(P[c][3] * inv)};
+      *reinterpret_cast<bf4*>(wh + base + col) = o;          // read by the next forward's cosine GEMM: cached store
+    }
+  }
+}
+
 // ================================================================= C-ABI
 static Margin mk_margin(float s, float m, int easy) {
   Margin r;
@@ -275,6 +328,22 @@ extern "C" int mmsim_arcface_rowfix(const void* dcos, const float* cosm, int ld,
   hipLaunchKernelGGL(arcface_rowfix_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)dcos, cosm, ld,
                      inv_w, rowvec, B, C);
   return mmsim_check_launch("arcface_rowfix");
+}
+
+extern "C" int mmsim_adamw_rows_l2norm(float* p, const float* g, float* m, float* v, void* w_hat, float* inv_norm, int R, int D,
+                                       float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                       float l2_eps, void* stream) {
+  MMSIM_REQUIRE(p && g && m && v && w_hat && inv_norm && R > 0 && D > 0, "adamw_rows_l2norm: null operand");
+  MMSIM_REQUIRE(D % 4 == 0 && D <= 4096, "adamw_rows_l2norm: D must be a multiple of 4 and <= 4096");
+  MMSIM_REQUIRE(step >= 1, "adamw: step is 1-based");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const dim3 grid((R + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define ARL(MC) hipLaunchKernelGGL((adamw_rows_l2norm_kernel<MC>), grid, block, 0, s, p, g, m, v, (bf16*)w_hat, inv_norm, R, D, lr, beta1, \
+                                   beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, l2_eps)
+  if (D <= 1024) ARL(4); else if (D <= 2048) ARL(8); else if (D <= 3072) ARL(12); else ARL(16);
+#undef ARL
+  return mmsim_check_launch("adamw_rows_l2norm");
 }
 
 static int grid_for(size_t n, int per_block) {

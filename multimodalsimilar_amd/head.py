@@ -18,6 +18,8 @@ from ._lib import MmsimError
 
 # MMSIM_HEAD_FUSED_DW=0: weight gradient through an fp32 dW_hat buffer + a separate normalise-backward pass (A/B switch)
 _FUSED_DW = os.environ.get("MMSIM_HEAD_FUSED_DW", "1") != "0"
+# MMSIM_HEAD_FUSED_NORM=0: F.normalize(weight) as its own pass in every forward instead of out of the AdamW launch
+_FUSED_NORM = os.environ.get("MMSIM_HEAD_FUSED_NORM", "1") != "0"
 
 
 def _margin_consts(m):
@@ -40,6 +42,7 @@ class ArcMarginProduct(nn.Module):
         self.easy_margin = easy_margin
         self.cos_m, self.sin_m, self.th, self.mm = _margin_consts(m)                 # arcface.py:28-33
         self._scratch = {}
+        self._wh_key = None           # (weight version, address) the cached F.normalize(weight) belongs to
         self.grad_ready_hook = None
 
     def update_m(self, delta):                                                       # arcface.py:35-42
@@ -54,6 +57,7 @@ class ArcMarginProduct(nn.Module):
         self.weight.data = self._flat.view("weight")
         self.weight.grad = None
         self._scratch = {}
+        self._wh_key = None
         return self
 
     def flat_buffers(self):
@@ -70,8 +74,22 @@ class ArcMarginProduct(nn.Module):
     def __getstate__(self):
         st = self.__dict__.copy()
         st["_scratch"] = {}
+        st["_wh_key"] = None
         st["grad_ready_hook"] = None
         return st
+
+    # ---- F.normalize(self.weight) out of the optimiser launch (FusedAdamW): see mmsim_adamw_rows_l2norm
+    def adamw_row_buffers(self):
+        C, D = self.out_feature, self.in_feature
+        if not _FUSED_NORM or not self.weight.is_cuda or D % 4 or D > 4096:
+            return None
+        return C, D, self._buf("wh", (C, D), torch.bfloat16), self._buf("inv_w", (C,), torch.float32)
+
+    def mark_normalised(self):
+        self._wh_key = (self.weight._version, self.weight.data_ptr())
+
+    def invalidate_normalised(self):
+        self._wh_key = None
 
     def _buf(self, name, shape, dtype, zero=False):
         key = (name, tuple(shape), dtype)
@@ -96,7 +114,10 @@ class ArcMarginProduct(nn.Module):
         xh = self._buf("xh", (B, D), torch.bfloat16)
         inv_x = self._buf("inv_x", (B,), torch.float32)
         cos = self._buf("cos", (B, ldc), torch.float32, zero=True)
-        ops.l2norm_fwd(self.weight.detach(), None, wh, 0, inv_w)                     # F.normalize(self.weight)
+        key = (self.weight._version, self.weight.data_ptr())
+        if self._wh_key != key:               # otherwise w_hat is current: left by the last AdamW launch, or the weights are static
+            ops.l2norm_fwd(self.weight.detach(), None, wh, 0, inv_w)                 # F.normalize(self.weight)
+            self._wh_key = key
         ops.l2norm_fwd(x, None, xh, 0, inv_x)                                        # F.normalize(x)
         ops.gemm(xh, wh, cos[:, :C])                                                 # F.linear  (arcface.py:47)
         return cos, dict(x=x, xh=xh, wh=wh, inv_x=inv_x, inv_w=inv_w, B=B, ldc=ldc)

@@ -258,3 +258,17 @@ def adamw_step(p, g, m, v, shadow, lr, beta1, beta2, eps, weight_decay, step, gr
         _chk(shadow, BF16, "adamw.shadow", 1)
     lib.adamw_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
                    float(weight_decay), int(step), float(grad_scale), _stream())
+
+
+def adamw_rows_l2norm(p2d, g2d, m2d, v2d, w_hat, inv_norm, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, l2_eps=1e-12):
+    """AdamW on a [R, D] weight matrix that also leaves F.normalize(weight) (bf16) and 1/||row|| for the next forward."""
+    R, D = p2d.shape
+    for t, n in ((p2d, "p"), (g2d, "g"), (m2d, "m"), (v2d, "v")):
+        _chk(t, F32, "adamw_rows." + n, 2)
+        if tuple(t.shape) != (R, D) or not t.is_contiguous():
+            raise ValueError("adamw_rows: p, g, m, v must be contiguous [R, D]")
+    _chk(w_hat, BF16, "adamw_rows.w_hat", 2); _chk(inv_norm, F32, "adamw_rows.inv_norm", 1)
+    if tuple(w_hat.shape) != (R, D) or not w_hat.is_contiguous() or inv_norm.numel() != R:
+        raise ValueError("adamw_rows: w_hat [R, D] contiguous and inv_norm [R] required")
+    lib.adamw_rows_l2norm(_p(p2d), _p(g2d), _p(m2d), _p(v2d), _p(w_hat), _p(inv_norm), R, D, float(lr), float(beta1), float(beta2),
+                          float(eps), float(weight_decay), int(step), float(grad_scale), float(l2_eps), _stream())

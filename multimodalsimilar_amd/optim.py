@@ -50,6 +50,13 @@ class FusedAdamW(torch.optim.Optimizer):
                     seen.add(id(p))
                     params.append(p)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # modules whose flat buffer is ONE row-normalised weight matrix (ArcMarginProduct): their update also leaves w_hat
+        self._row_owners = {}
+        for root in modules:
+            for m in root.modules():
+                if hasattr(m, "adamw_row_buffers") and hasattr(m, "flat_buffers"):
+                    for f in m.flat_buffers():
+                        self._row_owners[id(f)] = m
         self.grad_scale = grad_scale
         self._t = 0
         self._mv = {}
@@ -72,9 +79,22 @@ class FusedAdamW(torch.optim.Optimizer):
             if mv is None or mv[0].device != f.master.device:
                 mv = (torch.zeros_like(f.master), torch.zeros_like(f.master))
                 self._mv[id(f)] = mv
+            rn = self._row_owners.get(id(f))
+            rows = rn.adamw_row_buffers() if rn is not None else None
+            if rows is not None:
+                # a row-normalised weight matrix (the ArcFace head): the update also leaves F.normalize(weight) for the next forward
+                R, D, w_hat, inv_norm = rows
+                n = R * D
+                ops.adamw_rows_l2norm(f.master[:n].view(R, D), f.grad[:n].view(R, D), mv[0][:n].view(R, D), mv[1][:n].view(R, D),
+                                      w_hat, inv_norm, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._t,
+                                      self.grad_scale)
+                rn.mark_normalised()
+                continue
             ops.adamw_step(f.master, f.grad, mv[0], mv[1], f.shadow, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                            g["weight_decay"], self._t, self.grad_scale)
             f._shadow_version = f.master._version
+            if rn is not None:
+                rn.invalidate_normalised()          # the master changed under the module: its cached w_hat is stale
         return None
 
     # ---- checkpointing (the reference saves optimiser dicts next to the model, cv_classifier_train_daodian.py:298-306)

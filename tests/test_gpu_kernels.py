@@ -297,3 +297,56 @@ def test_head_weight_gradient_rowfix_epilogue(C, D, B):
     assert relerr(out - prev, w.grad) < 1e-2               # w_hat enters the correction bf16-rounded: 2^-9-class differences
     with pytest.raises(Exception):
         ops.gemm(dcos_p[:, :C], xh, out.bfloat16(), trans_a=True, b_kmajor=False, bias=rowvec, epilogue=ops.EPI_ROWFIX, aux_in=wh)
+
+
+@pytest.mark.parametrize("R,D", [(37, 1408), (200, 2816), (5, 64), (9, 4096)])
+def test_adamw_rows_l2norm_equals_adamw_then_normalize(R, D):
+    """mmsim_adamw_rows_l2norm = mmsim_adamw_step followed by F.normalize of the updated rows (arcface.py:47)."""
+    ops = _ops()
+    p0, g = rnd(R, D, scale=0.1, seed=1), rnd(R, D, scale=0.01, seed=2)
+    m0, v0 = rnd(R, D, scale=0.01, seed=3), rnd(R, D, scale=0.01, seed=4).abs() * 1e-3
+    hp = dict(lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=3, grad_scale=0.5)
+    pa, ma, va = p0.clone().view(-1), m0.clone().view(-1), v0.clone().view(-1)
+    ops.adamw_step(pa, g.view(-1), ma, va, None, hp["lr"], hp["beta1"], hp["beta2"], hp["eps"], hp["weight_decay"], hp["step"], hp["grad_scale"])
+    pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+    wh = torch.empty(R, D, dtype=torch.bfloat16, device=DEV)
+    inv = torch.empty(R, device=DEV)
+    ops.adamw_rows_l2norm(pb, g, mb, vb, wh, inv, hp["lr"], hp["beta1"], hp["beta2"], hp["eps"], hp["weight_decay"], hp["step"], hp["grad_scale"])
+    assert relerr(pb.view(-1), pa) < 1e-6 and relerr(mb.view(-1), ma) < 1e-6 and relerr(vb.view(-1), va) < 1e-6
+    assert relerr(inv, 1.0 / pb.norm(dim=1)) < 1e-6
+    assert relerr(wh, F.normalize(pb)) < 1e-2
+
+
+def test_head_reuses_the_normalised_weights_only_while_they_are_current():
+    """ArcMarginProduct keeps F.normalize(weight) from the optimiser launch / the previous forward; any torch-side write to the
+    weight (version bump) or an update through the plain AdamW path must make the next forward renormalise."""
+    from multimodalsimilar_amd import head as H
+    from multimodalsimilar_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    mod = H.ArcMarginProduct(64, 40, m=0.3).to(DEV)
+    x = rnd(6, 64, seed=5)
+    label = torch.arange(6, device=DEV)
+    opt = FusedAdamW(mod, lr=1e-2)
+    def ref_cos():
+        return F.normalize(x) @ F.normalize(mod.weight.detach()).t()
+    for it in range(3):
+        loss, _ = mod.forward_loss(x.clone().requires_grad_(True), label)
+        loss.backward()
+        opt.step(); opt.zero_grad()
+        with torch.no_grad():
+            assert relerr(mod.forward_test(x), ref_cos()) < 1e-2            # uses the w_hat the AdamW launch left
+        assert mod._wh_key is not None
+    with torch.no_grad():
+        mod.weight.mul_(-1.0)                                               # torch-side write: version bump
+        assert relerr(mod.forward_test(x), ref_cos()) < 1e-2
+    old = H._FUSED_NORM
+    try:
+        H._FUSED_NORM = False                                               # plain AdamW path: must invalidate the cache
+        loss, _ = mod.forward_loss(x.clone().requires_grad_(True), label)
+        loss.backward()
+        opt.step(); opt.zero_grad()
+        assert mod._wh_key is None
+        with torch.no_grad():
+            assert relerr(mod.forward_test(x), ref_cos()) < 1e-2
+    finally:
+        H._FUSED_NORM = old
