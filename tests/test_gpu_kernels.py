@@ -295,6 +295,9 @@ def test_head_weight_gradient_rowfix_epilogue(C, D, B):
     out = prev.clone()
     ops.gemm(dcos_p[:, :C], xh, out, trans_a=True, b_kmajor=False, bias=rowvec, epilogue=ops.EPI_ROWFIX, aux_in=wh, accumulate=True)
     assert relerr(out - prev, w.grad) < 1e-2               # w_hat enters the correction bf16-rounded: 2^-9-class differences
+    out2 = torch.full_like(prev, 7.0)                      # store form: previous contents ignored
+    ops.gemm(dcos_p[:, :C], xh, out2, trans_a=True, b_kmajor=False, bias=rowvec, epilogue=ops.EPI_ROWFIX, aux_in=wh)
+    assert torch.equal(out2, out - prev) or relerr(out2, out - prev) < 1e-5
     with pytest.raises(Exception):
         ops.gemm(dcos_p[:, :C], xh, out.bfloat16(), trans_a=True, b_kmajor=False, bias=rowvec, epilogue=ops.EPI_ROWFIX, aux_in=wh)
 
@@ -350,3 +353,4 @@ def test_head_reuses_the_normalised_weights_only_while_they_are_current():
             assert relerr(mod.forward_test(x), ref_cos()) < 1e-2
     finally:
         H._FUSED_NORM = old
+
