@@ -258,17 +258,31 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
       dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vreg[kk], dP, 0, 0, 0);
     }
     // X[r] -> P (dropped, for dV) ; dP[r] -> dS
+    // Dropout mask: one hash serves the elements (q, key) and (q, key ^ 1), which sit on NEIGHBOURING LANES here (lane = key).
+    // For the register pair (r, r + 1) = queries (q, q + 1) the even lane hashes q, the odd lane q + 1, and a quad-perm DPP
+    // move swaps the results: 8 hashes + 8 moves per 16 elements instead of 16 hashes.
+    const int par = key & 1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh, q = 32 * qt + ql;
-      const float pr = __expf(X[r] * p.scale + mbk - lse[q]);
-      float ks = 1.0f;
-      if (p.thresh) {
-        const unsigned long long idx = ((unsigned long long)bh * S + q) * S + key;
-        ks = drop_keep16(drop_bits(dkey, idx >> 1), key & 1, p.thresh) ? p.inv_keep : 0.f;
+    for (int r = 0; r < 16; r += 2) {
+      uint32_t bits0 = 0u, bits1 = 0u;
+      if (p.thresh) {                       // kernel argument: wave-uniform, EXEC stays full for the DPP move
+        const int qm = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * hh + par;
+        const unsigned long long idx = ((unsigned long long)bh * S + qm) * S + key;
+        const uint32_t mine = drop_bits(dkey, idx >> 1);
+        const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+        bits0 = par ? other : mine;
+        bits1 = par ? mine : other;
       }
-      X[r] = pr * ks;
-      dP[r] = pr * (dP[r] * ks - dl[ql]);
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int rr = r + k2;
+        const int ql = (rr & 3) + 8 * (rr >> 2) + 4 * hh, q = 32 * qt + ql;
+        const float pr = __expf(X[rr] * p.scale + mbk - lse[q]);
+        float ks = 1.0f;
+        if (p.thresh) ks = drop_keep16(k2 ? bits1 : bits0, par, p.thresh) ? p.inv_keep : 0.f;
+        X[rr] = pr * ks;
+        dP[rr] = pr * (dP[rr] * ks - dl[ql]);
+      }
     }
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
