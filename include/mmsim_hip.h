@@ -40,6 +40,13 @@ int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, const void* 
                     void* C, int ldc, int c_is_f32, const float* bias, int epilogue, const void* aux_in,
                     void* aux_out, int ld_aux, float alpha, int split_k, int accumulate, void* stream);
 
+/* Two weight gradients of one layer in ONE launch: C1[M1,N] += A1^T B1 and C2[M2,N] += A2^T B2 (A = dY stored [K][M],
+ * B = X stored [K][N], f32 C, split-K atomics; M1, M2, N multiples of 256, K of 64).  The attention-output (16 tiles) and
+ * q|k|v (48 tiles) weight gradients of a BERT layer (autograd of modeling_bert.py:174-176, 289) fill the chip together. */
+int mmsim_gemm_bf16_wgrad_pair(int M1, int M2, int N, int K, const void* A1, int lda1, const void* B1, int ldb1, float* C1,
+                               int ldc1, const void* A2, int lda2, const void* B2, int ldb2, float* C2, int ldc2, int split_k,
+                               void* stream);
+
 /* 1x1 conv whose input is the previous BatchNorm + SiLU (+ squeeze-excite gate) applied while the operand is
  * staged: x -> silu(xf_scale[c] x + xf_shift[c]) * xf_gate[pixel / xf_hw, c]  (gate may be NULL); with xf_scale = xf_shift =
  * NULL the operand is already activated (mmsim_pool_bn_act_store) and only x -> x * gate remains.

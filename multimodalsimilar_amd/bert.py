@@ -28,6 +28,8 @@ from ._lib import MmsimError
 # intermediate.dense bias in the dX GEMM epilogue measured SLOWER on cfg4 (+1 ms/step: the epilogue is on the GEMM's critical
 # path, the column-sum pass it saves overlaps with the image tower's stream anyway) and was removed.
 _FUSE_ATTN_BIAS = os.environ.get("MMSIM_FUSE_BIAS_GRADS", "1") != "0"
+# MMSIM_WGRAD_PAIR=0: the attention-output and q|k|v weight gradients of a layer as two launches instead of one grouped launch
+_WGRAD_PAIR = os.environ.get("MMSIM_WGRAD_PAIR", "1") != "0"
 
 class BertConfig:
     """The subset of HF BertConfig the tower needs (defaults: hfl/chinese-roberta-wwm-ext)."""
@@ -293,6 +295,8 @@ class BertModel(nn.Module):
         skH = ops.pick_split_k(H, H, M)
         skI = ops.pick_split_k(I, H, M)
         sk3 = ops.pick_split_k(3 * H, H, M)
+        pair = _WGRAD_PAIR and ops.wgrad_pair_eligible(3 * H, H, H, M)
+        sk_pair = ops.pick_split_k(4 * H, H, M) if pair else 1
         for li in range(L - 1, -1, -1):
             p = f"encoder.layer.{li}."
             st = ws.st[li]
@@ -316,8 +320,10 @@ class BertModel(nn.Module):
                        ws.dt if m.ph > 0 else None, G(p + "attention.output.LayerNorm.weight"),
                        G(p + "attention.output.LayerNorm.bias"), G(p + "attention.output.dense.bias"), m.ph, m.seed,
                        4 * li + 1)
-            ops.gemm(dT, ws.ctx[li], G(p + "attention.output.dense.weight"), trans_a=True, b_kmajor=False, split_k=skH,
-                     accumulate=True)
+            dT_o = dT
+            if not pair:
+                ops.gemm(dT, ws.ctx[li], G(p + "attention.output.dense.weight"), trans_a=True, b_kmajor=False, split_k=skH,
+                         accumulate=True)
             ops.gemm(dT, SV(p + "attention.output.dense.weight"), ws.dctx, b_kmajor=False)
             # ---- attention
             qkv_db = fl._view(fl.grad, p + "attention.self.query.bias", (3 * H,))
@@ -325,8 +331,12 @@ class BertModel(nn.Module):
                          dbias=qkv_db if _FUSE_ATTN_BIAS else None)                               # + the q|k|v bias gradients
             if not _FUSE_ATTN_BIAS:
                 ops.colsum(ws.dqkv, qkv_db)
-            ops.gemm(ws.dqkv, ws.h[li], fl._view(fl.grad, p + "attention.self.query.weight", (3 * H, H)), trans_a=True,
-                     b_kmajor=False, split_k=sk3, accumulate=True)
+            if pair:      # q|k|v (48 tiles) and attention-output (16 tiles) weight gradients as one 256-block launch
+                ops.gemm_wgrad_pair(ws.dqkv, ws.h[li], fl._view(fl.grad, p + "attention.self.query.weight", (3 * H, H)),
+                                    dT_o, ws.ctx[li], G(p + "attention.output.dense.weight"), sk_pair)
+            else:
+                ops.gemm(ws.dqkv, ws.h[li], fl._view(fl.grad, p + "attention.self.query.weight", (3 * H, H)), trans_a=True,
+                         b_kmajor=False, split_k=sk3, accumulate=True)
             nxt = ws.dh[1] if dh is ws.dh[0] else ws.dh[0]
             ops.gemm(ws.dqkv, fl.sview(p + "attention.self.query.weight", (3 * H, H)), nxt, b_kmajor=False,
                      epilogue=ops.EPI_ADD, aux_in=dy1)

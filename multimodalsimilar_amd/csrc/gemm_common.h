@@ -11,6 +11,10 @@ struct GemmParams {
   const float* xf_scale; const float* xf_shift; const float* xf_gate; int xf_hw, xf_C; FastDiv xf_dhw;
   int band;       // gemm_pp64_kernel: tile-rows per band of the tile walk
   float* stats;   // gemm_bf16_kernel, bf16 output, no split: per-M-tile column sum / sumsq slab [tiles_m][2][N] (NULL = off)
+  // gemm_pp64_kernel<.., GRP = true>: a SECOND product of the same N, K, layouts and split count in the same launch -- tile-rows
+  // >= tiles_m1 belong to it (A2 / B2 / C2).  Used to run the attention-output and the q|k|v weight gradients of a layer as
+  // one 256-block launch (16 + 48 output tiles x 4 splits) instead of two launches that each under-fill the chip.
+  const bf16* A2; const bf16* B2; void* C2; int lda2, ldb2, ldc2, tiles_m1;
   int dbg;   // ablation switches for tools/bench_gemm.py (MMSIM_GEMM_DBG): 1 no DMA, 2 no LDS reads, 4 no MFMA; 0 in production
 };
 

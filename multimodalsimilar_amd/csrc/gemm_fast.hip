@@ -15,6 +15,7 @@
 // gemm_fast_kernel, per step t:  wait(tile t landed: vmcnt(6) leaves tile t+1 in flight) -> s_barrier -> issue tile t+2
 // into the slot read in step t-1 (every wave has passed the barrier) -> 32 MFMAs per wave on tile t.
 #include "gemm_common.h"
+#include <string.h>
 #include <stdlib.h>
 
 #define FBM 256
@@ -203,7 +204,7 @@ __device__ __forceinline__ bf8 hfrag(const char* lds, int rbase, int ks, int lan
   }
 }
 
-template <bool TA, bool TB_KMAJOR, int BN>
+template <bool TA, bool TB_KMAJOR, int BN, bool GRP = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
   constexpr int MT = BN == 256 ? 8 : 4;
   constexpr int WROWS = MT * 16;
@@ -228,7 +229,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
   const int band = tile / (p.band * p.tiles_n), within = tile - band * (p.band * p.tiles_n);
   const int rows = min(p.band, p.tiles_m - band * p.band);
   const int tn = within / rows, tm = band * p.band + (within - tn * rows);
-  const int m0 = tm * GBM, n0 = tn * BN;
+  // grouped launch: the tile-rows past tiles_m1 are the second product's (workgroup-uniform switch of the operand pointers)
+  const bool second = GRP && tm >= p.tiles_m1;
+  const bf16* gA = second ? p.A2 : p.A;
+  const bf16* gB = second ? p.B2 : p.B;
+  const int glda = second ? p.lda2 : p.lda, gldb = second ? p.ldb2 : p.ldb;
+  const int m0 = (second ? tm - p.tiles_m1 : tm) * GBM, n0 = tn * BN;
   const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int ns = (kend - kbeg) / 64;
@@ -241,9 +247,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
 
   const bool dma_on = !(p.dbg & 1);
   if (dma_on) {
-    dma_tile<TA, GBM>(p.A, p.lda, m0, kbeg, smem, wave, lane);
-    dma_tile<!TB_KMAJOR, BN>(p.B, p.ldb, n0, kbeg, smem + B_OFF, wave, lane);
-    if (ns > 1) dma_tile<TA, GBM>(p.A, p.lda, m0, kbeg + 64, smem + A_UNIT, wave, lane);
+    dma_tile<TA, GBM>(gA, glda, m0, kbeg, smem, wave, lane);
+    dma_tile<!TB_KMAJOR, BN>(gB, gldb, n0, kbeg, smem + B_OFF, wave, lane);
+    if (ns > 1) dma_tile<TA, GBM>(gA, glda, m0, kbeg + 64, smem + A_UNIT, wave, lane);
   }
   if (ns > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LPU) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     PP64_READ(0)
     if (u + 1 < ns && dma_on)
-      dma_tile<!TB_KMAJOR, BN>(p.B, p.ldb, n0, kbeg + (u + 1) * 64, smem + B_OFF + ((u + 1) & 1) * B_UNIT, wave, lane);
+      dma_tile<!TB_KMAJOR, BN>(gB, gldb, n0, kbeg + (u + 1) * 64, smem + B_OFF + ((u + 1) & 1) * B_UNIT, wave, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PP64_MFMA()
     // ---- odd step: k-half 1 of slice u
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     PP64_READ(1)
     if (u + 2 < ns) {
       int sn = sa + 2; if (sn >= 3) sn -= 3;
-      if (dma_on) dma_tile<TA, GBM>(p.A, p.lda, m0, kbeg + (u + 2) * 64, smem + sn * A_UNIT, wave, lane);
+      if (dma_on) dma_tile<TA, GBM>(gA, glda, m0, kbeg + (u + 2) * 64, smem + sn * A_UNIT, wave, lane);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LPU) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -311,6 +317,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     f4 (&a4)[4][4] = *reinterpret_cast<f4 (*)[4][4]>(&acc[half * 4][0]);
     const int row0 = m0 + wm * WROWS + half * 64, col0 = n0 + wn * 64;
     if (!p.c_f32) fast_epilogue_epi<0>(p, a4, row0, col0, lane, fs, stg);
+    else if (GRP && second) {              // the second product's output (grouped launches are split-K atomics only)
+      GemmParams q = p;
+      q.C = p.C2; q.ldc = p.ldc2;
+      fast_epilogue<EPI_NONE, 3>(q, a4, row0, col0, lane, fs, stg);
+    }
     else if (p.atomic) fast_epilogue<EPI_NONE, 3>(p, a4, row0, col0, lane, fs, stg);
     else if (p.accum) fast_epilogue<EPI_NONE, 2>(p, a4, row0, col0, lane, fs, stg);
     else if (p.epi == EPI_TANH) fast_epilogue<EPI_TANH, 1>(p, a4, row0, col0, lane, fs, stg);
@@ -404,4 +415,39 @@ void gemm_fast_launch(GemmParams p, int trans_a, int b_kmajor, int splits, hipSt
   else if (!trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_fast_kernel<false, false>), grid, block, lds, s, p);
   else if (trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_fast_kernel<true, false>), grid, block, lds, s, p);
   else hipLaunchKernelGGL((gemm_fast_kernel<true, true>), grid, block, lds, s, p);
+}
+
+// Two weight-gradient products of one layer as ONE launch of the pipelined kernel: C1[M1,N] += A1^T B1 and C2[M2,N] += A2^T B2,
+// all operands stored [K][.] (dY and X as they lie in memory), f32 outputs through split-K atomics.  See GemmParams::A2.
+extern "C" int mmsim_gemm_bf16_wgrad_pair(int M1, int M2, int N, int K, const void* A1, int lda1, const void* B1, int ldb1, float* C1,
+                                          int ldc1, const void* A2, int lda2, const void* B2, int ldb2, float* C2, int ldc2, int split_k,
+                                          void* stream) {
+  MMSIM_REQUIRE(A1 && B1 && C1 && A2 && B2 && C2, "gemm_wgrad_pair: null operand");
+  MMSIM_REQUIRE(M1 > 0 && M2 > 0 && M1 % GBM == 0 && M2 % GBM == 0 && N > 0 && N % 256 == 0 && K > 0 && K % 64 == 0,
+                "gemm_wgrad_pair: M1, M2, N must be multiples of 256 and K of 64");
+  MMSIM_REQUIRE(split_k >= 1, "gemm_wgrad_pair: split_k >= 1");
+  MMSIM_REQUIRE(lda1 >= M1 && lda2 >= M2 && ldb1 >= N && ldb2 >= N && ldc1 >= N && ldc2 >= N, "gemm_wgrad_pair: leading dimension too small");
+  MMSIM_REQUIRE((lda1 % 8) == 0 && (lda2 % 8) == 0 && (ldb1 % 8) == 0 && (ldb2 % 8) == 0 && (ldc1 % 4) == 0 && (ldc2 % 4) == 0,
+                "gemm_wgrad_pair: lda / ldb must be multiples of 8, ldc of 4");
+  MMSIM_REQUIRE(((uintptr_t)A1 % 16) == 0 && ((uintptr_t)B1 % 16) == 0 && ((uintptr_t)C1 % 16) == 0 && ((uintptr_t)A2 % 16) == 0 &&
+                    ((uintptr_t)B2 % 16) == 0 && ((uintptr_t)C2 % 16) == 0, "gemm_wgrad_pair: operands must be 16-byte aligned");
+  int kps = (K + split_k - 1) / split_k;
+  kps = ((kps + 63) / 64) * 64;
+  const int splits = (K + kps - 1) / kps;
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = (const bf16*)A1; p.B = (const bf16*)B1; p.C = C1; p.lda = lda1; p.ldb = ldb1; p.ldc = ldc1;
+  p.A2 = (const bf16*)A2; p.B2 = (const bf16*)B2; p.C2 = C2; p.lda2 = lda2; p.ldb2 = ldb2; p.ldc2 = ldc2;
+  p.M = M1 + M2; p.N = N; p.K = K; p.c_f32 = 1; p.epi = EPI_NONE; p.atomic = 1; p.alpha = 1.0f; p.k_per_split = kps;
+  p.tiles_m1 = M1 / GBM; p.tiles_m = (M1 + M2) / GBM; p.tiles_n = N / 256; p.splits = splits; p.xf_hw = 1; p.xf_dhw = make_fastdiv(1);
+  { const char* e = getenv("MMSIM_GEMM_BAND"); p.band = e ? atoi(e) : 8; if (p.band < 1) p.band = 1; }
+  const size_t lds_stage = 8 * 64 * EP_PITCH * 4, lds_ring = 3 * GBM * 128 + 2 * 256 * 128;
+  const size_t lds = lds_ring > lds_stage ? lds_ring : lds_stage;
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)gemm_pp64_kernel<true, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    done = true;
+  }
+  hipLaunchKernelGGL((gemm_pp64_kernel<true, false, 256, true>), dim3(p.tiles_m * p.tiles_n * splits), dim3(512), lds, (hipStream_t)stream, p);
+  return mmsim_check_launch("gemm_wgrad_pair");
 }

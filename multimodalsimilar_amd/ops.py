@@ -120,6 +120,23 @@ def gemm(a, b, c, *, trans_a=False, b_kmajor=True, bias=None, epilogue=EPI_NONE,
     return c
 
 
+def wgrad_pair_eligible(M1, M2, N, K):
+    return M1 % 256 == 0 and M2 % 256 == 0 and N % 256 == 0 and K % 64 == 0 and (M1 + M2) // 256 * (N // 256) >= 32
+
+
+def gemm_wgrad_pair(a1, b1, c1, a2, b2, c2, split_k):
+    """c1[M1,N] += a1^T b1 and c2[M2,N] += a2^T b2 in one launch (a: [K, M], b: [K, N] bf16; c: f32); see mmsim_gemm_bf16_wgrad_pair."""
+    for t, n in ((a1, "a1"), (b1, "b1"), (a2, "a2"), (b2, "b2")):
+        _chk(t, BF16, "gemm_wgrad_pair." + n, 2)
+    _chk(c1, F32, "gemm_wgrad_pair.c1", 2); _chk(c2, F32, "gemm_wgrad_pair.c2", 2)
+    K, M1 = a1.shape
+    M2, N = a2.shape[1], b1.shape[1]
+    if a2.shape[0] != K or b1.shape[0] != K or b2.shape[0] != K or b2.shape[1] != N or tuple(c1.shape) != (M1, N) or tuple(c2.shape) != (M2, N):
+        raise ValueError("gemm_wgrad_pair: shape mismatch")
+    lib.gemm_bf16_wgrad_pair(M1, M2, N, K, _p(a1), _ld(a1), _p(b1), _ld(b1), _p(c1), _ld(c1), _p(a2), _ld(a2), _p(b2), _ld(b2), _p(c2),
+                             _ld(c2), int(split_k), _stream())
+
+
 def pick_split_k(M, N, K):
     """Split-K factor for wgrad-style products (few output tiles, long reduction).  Mirrors the tile choice of
     csrc/gemm_fast.hip: outputs with >= 32 tiles of 256x256 run the pipelined 256x256 kernel with ~192-256 blocks,

@@ -354,3 +354,17 @@ def test_head_reuses_the_normalised_weights_only_while_they_are_current():
     finally:
         H._FUSED_NORM = old
 
+
+
+@pytest.mark.parametrize("M1,M2,N,K,sk", [(768, 256, 256, 1024, 2), (512, 512, 512, 640, 1), (3072, 1024, 1024, 2048, 4)])
+def test_grouped_weight_gradient_pair(M1, M2, N, K, sk):
+    """mmsim_gemm_bf16_wgrad_pair: two dY^T X products of one launch, accumulated into non-zero f32 buffers."""
+    ops = _ops()
+    a1, b1 = rnd(K, M1, seed=1).bfloat16(), rnd(K, N, seed=2).bfloat16()
+    a2, b2 = rnd(K, M2, seed=3).bfloat16(), rnd(K, N, seed=4).bfloat16()
+    c1, c2 = rnd(M1, N, seed=5), rnd(M2, N, seed=6)
+    r1, r2 = c1 + a1.float().t() @ b1.float(), c2 + a2.float().t() @ b2.float()
+    ops.gemm_wgrad_pair(a1, b1, c1, a2, b2, c2, sk)
+    assert relerr(c1, r1) < 2e-3 and relerr(c2, r2) < 2e-3
+    with pytest.raises(Exception):
+        ops.gemm_wgrad_pair(a1[:, :100], b1, c1[:100], a2, b2, c2, sk)

@@ -209,7 +209,13 @@ def test_text_tower_against_oracle_fresh_inputs():
     loss.backward()
     assert abs(loss.item() - ref_loss.item()) < 2e-2 * ref_loss.item()
     named = dict(model.ptm.named_parameters())
+    # width 768 at 512 tokens is the smallest shape whose q|k|v and attention-output weight gradients leave as ONE grouped
+    # launch (ops.wgrad_pair_eligible): both of its outputs are compared
+    from multimodalsimilar_amd import ops
+    assert ops.wgrad_pair_eligible(3 * 768, 768, 768, B * S)
     for k in ("pooler.dense.weight", "encoder.layer.1.output.dense.weight", "encoder.layer.0.attention.self.key.weight",
+              "encoder.layer.1.attention.self.value.weight", "encoder.layer.0.attention.output.dense.weight",
+              "encoder.layer.1.attention.output.dense.weight",
               "encoder.layer.0.intermediate.dense.bias", "embeddings.LayerNorm.weight",
               "embeddings.position_embeddings.weight"):
         assert relerr(named[k].grad, sdr[k].grad) < 6e-2, k
