@@ -90,3 +90,27 @@ def finish_batch(collated, transform, device):
     out = {k: v.to(device, non_blocking=True) for k, v in collated.items() if k != "images"}
     out["img_tensor"] = transform.batch(collated["images"])
     return out
+
+
+class TitleDataset(torch.utils.data.Dataset):
+    """Text-only rows of the reference's nlp_classifier_train.py (:78-87: csv with ``spu_name`` and ``cateid``; titles cleaned by
+    ``preprocess_for_infer``, tokenised with padding='max_length', max_length=128, truncation=True; ``cateid`` becomes ``labels``)."""
+
+    def __init__(self, tokenizer, csv_path, text_col="spu_name", label_col="cateid", max_length=128):
+        from pandas import read_csv
+        self.dataframe = read_csv(csv_path)
+        self.tokenizer, self.text_col, self.label_col, self.max_length = tokenizer, text_col, label_col, max_length
+
+    def __len__(self):
+        return len(self.dataframe)
+
+    def __getitem__(self, index):
+        tok = self.tokenizer(text=preprocess_for_infer([str(self.dataframe[self.text_col][index])])[0], padding="max_length",
+                             max_length=self.max_length, truncation=True)
+        return tok, torch.tensor(int(self.dataframe[self.label_col][index]), dtype=torch.int64)
+
+
+def collate_titles(batch):
+    out = {k: torch.tensor([list(t[k]) for t, _ in batch], dtype=torch.int64) for k in ("input_ids", "token_type_ids", "attention_mask")}
+    out["labels"] = torch.stack([y for _, y in batch])
+    return out

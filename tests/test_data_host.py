@@ -53,3 +53,14 @@ def test_dataset_and_collate_follow_the_reference_contract(tmp_path):
     assert int(b["attention_mask"][0].sum()) < 32                    # padded to max_length, as the reference pads
     ds2 = D.MultimodalDataset(tokenizer=tok, transform=None, csv_path=csv, img_path=img_dir, use_label=False, max_length=32)
     assert "labels" not in D.collate_fn([ds2[0], ds2[1]])
+
+
+def test_title_dataset_follows_the_text_only_contract(tmp_path):
+    from multimodalsimilar_amd import data as D
+    csv, _, vocab = make_dataset(str(tmp_path))
+    tok = D.load_tokenizer(vocab)
+    ds = D.TitleDataset(tok, csv, max_length=16)
+    b = D.collate_titles([ds[0], ds[1], ds[4]])
+    assert b["labels"].tolist() == [0, 1, 1] and all(tuple(b[k].shape) == (3, 16) and b[k].dtype == torch.int64
+                                                     for k in ("input_ids", "token_type_ids", "attention_mask"))
+    assert b["input_ids"][:, 0].tolist() == [tok.cls_token_id] * 3

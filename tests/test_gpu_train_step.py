@@ -217,3 +217,13 @@ def test_entry_point_trains_on_the_reference_data_format(tmp_path):
     batch = D.finish_batch(D.collate_fn([ds[0], ds[5]]), tf, DEV)
     assert batch["img_tensor"].shape == (2, 3, 64, 64) and batch["input_ids"].shape == (2, 32) and batch["labels"].tolist() == [0, 2]
     assert np.array_equal(batch["img_tensor"][1].cpu().numpy(), P.eval_transform(ds[5][0], 64, 1.0))
+
+
+def test_text_only_entry_point_trains_on_the_reference_csv_format(tmp_path):
+    """nlp_classifier_train.main (BASELINE config 1's entry point) on a csv + local vocab.txt: two steps, finite parameters."""
+    from test_data_host import make_dataset
+    import nlp_classifier_train as entry
+    csv, _, vocab = make_dataset(str(tmp_path), n=9)
+    model = entry.main(["--train-csv", csv, "--vocab", vocab, "--text-model", "tiny", "--seq-len", "32", "--batch-size", "4",
+                        "--num-labels", "3", "--num-epochs", "1", "--num-workers", "2", "--log-every", "1", "--max-steps", "2"])
+    assert all(torch.isfinite(p).all() for p in model.parameters())
