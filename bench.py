@@ -128,9 +128,13 @@ def cpu_baseline(cfg, b_cpu, steps):
                                   margin={"multimodal": 0.5, "nlp": 0.4, "cv": 0.2}[kind])
     from multimodalsimilar_amd.train import synthetic_batch
     batch = synthetic_batch(cfg, "cpu", seed=4321, batch=b_cpu)
+    tw = time.perf_counter()
+    orc.step(batch)                             # one un-timed warm step (allocator, thread pool, first-touch of the weights)
+    warm = time.perf_counter() - tw
     t0 = time.perf_counter()
     done = 0
-    while done < steps and (done == 0 or time.perf_counter() - t0 < 25.0):     # bounded: stop once ~25 s are spent
+    # >= 2 timed steps; more only while the sample stays bounded (~30 s of CPU work in all)
+    while done < 2 or (done < steps and time.perf_counter() - t0 + warm < 30.0):
         orc.step(batch)
         done += 1
     steps = done
@@ -141,8 +145,8 @@ def cpu_baseline(cfg, b_cpu, steps):
     except Exception:
         pass
     return dict(value=b_cpu / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{steps} timed steps of the identical step at B_cpu={b_cpu} pairs (fp32, torch CPU ops via oracle/step_ref.py), "
-                       f"{dt:.2f} s/step; {ncores} threads on: {model}")
+                sample=f"{steps} timed steps (after 1 un-timed warm step) of the identical step at B_cpu={b_cpu} pairs (fp32, torch CPU ops "
+                       f"via oracle/step_ref.py), {dt:.2f} s/step; {ncores} threads on: {model}")
 
 
 def main():
@@ -152,7 +156,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg4")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (reported; invalid as the headline)")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=8, help="B_cpu of the cpu_baseline leg (SURVEY 8d: 8 or 16)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
@@ -257,7 +261,9 @@ def main():
                        "dropout": not args.no_dropout, "attention_mask": "ragged U{8..S}" if args.ragged_masks else "all ones", "loss_path": "literal" if args.literal_loss else "fused",
                        "algorithmic_gflop_per_pair": fpp / 1e9,
                        "step_mfma_frac": (fpp * cfg["batch"] / (ms * 1e-3) / 1e12) / MFMA_BF16_PEAK_TFLOPS,
-                       "final_loss": lossv},
+                       "final_loss": lossv,
+                       # every MMSIM_* switch set in this process (they select schedules / kernels): empty = the defaults
+                       "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MMSIM_")}},
             "roofline": None if g is None else {
                 "bound": "mfma", "kernel": "gemm_pp64_kernel<false,true,256> (Y = X W^T: 256x256 tiles, 64-deep LDS-DMA slices, ping-pong wave groups, bf16 MFMA 16x16x32, fp32 accumulate)",
                 "achieved": g["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / MFMA_BF16_PEAK_TFLOPS,

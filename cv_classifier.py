@@ -20,6 +20,24 @@ from multimodalsimilar_amd._lib import lib, MmsimError
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
 
+def load_timm_state_dict(backbone, sd):
+    """Load a timm-format EfficientNet state dict (what ``timm.create_model(..., pretrained=True)`` reads, cv_classifier.py:23;
+    file ``efficientnet_b4_ra2_320-7eb33cd5.pth``, cv_classifier_train.py:27) into the HIP backbone.  timm checkpoints carry the
+    ImageNet classifier the reference strips (``classifier.weight / .bias``, cv_classifier.py:24-27): those two keys are the ONLY
+    ones that may be unexpected; any other missing / unexpected / mis-shaped key raises instead of being skipped silently."""
+    sd = dict(sd.get("state_dict", sd)) if isinstance(sd, dict) else sd
+    for k in ("classifier.weight", "classifier.bias"):
+        sd.pop(k, None)
+    own = backbone.state_dict()
+    missing = [k for k in own if k not in sd]
+    unexpected = [k for k in sd if k not in own]
+    shapes = [k for k in sd if k in own and tuple(sd[k].shape) != tuple(own[k].shape)]
+    if missing or unexpected or shapes:
+        raise KeyError(f"timm state dict does not match {backbone.model_name}: missing {missing[:5]} (+{max(0, len(missing) - 5)}), "
+                       f"unexpected {unexpected[:5]} (+{max(0, len(unexpected) - 5)}), shape mismatch {shapes[:5]}")
+    backbone.load_state_dict(sd, strict=True)
+
+
 class CvClassifier(nn.Module):
     def __init__(self, model_name, fc_dim, num_labels, m=0.2, pretrained=True, use_fc=True):
         super().__init__()
@@ -27,7 +45,7 @@ class CvClassifier(nn.Module):
         if pretrained:
             path = os.path.join(os.environ.get("MMSIM_PRETRAINED_DIR", ""), model_name + ".pth")
             if os.path.isfile(path):
-                self.backbone.load_state_dict(torch.load(path, map_location="cpu"), strict=False)
+                load_timm_state_dict(self.backbone, torch.load(path, map_location="cpu"))
             else:
                 warnings.warn(f"CvClassifier: no local weights for {model_name!r} (offline; set MMSIM_PRETRAINED_DIR) - "
                               "the image tower is randomly initialised")

@@ -80,15 +80,22 @@ int mmsim_attn_bwd_dbias(const void* qkv, int ld_qkv, const long long* mask, con
                          unsigned long long seed, unsigned int stream_id, float* scratch, unsigned long long scratch_floats,
                          void* stream);
 
-/* ---- BERT embeddings: LayerNorm(word[ids] + type[tt] + pos[0..S)) then dropout (modeling_bert.py:68-108).
- * ids / token_types: int64 [B*S] (token_types may be NULL = zeros); tables and gamma/beta fp32; out bf16 [B*S,H].
+/* ---- BERT embeddings: LayerNorm(word[ids] + type[tt] + pos[position_ids]) then dropout (modeling_bert.py:68-108;
+ * position ids as forwarded by nlp_classifier.py:23-27 / transformer_emb.py:20-24).
+ * ids / token_types / position_ids: int64 [B*S] (token_types NULL = zeros; position_ids NULL = arange(S) per row);
+ * tables and gamma/beta fp32; out bf16 [B*S,H].  vocab_size / type_vocab_size (<= 2) / max_positions are the table
+ * heights: an index outside its table sets *err_flag (device int, never cleared by the kernels; nn.Embedding raises an
+ * IndexError there) and is clamped, so neither the gather nor the backward's scatter-add leaves its table.
  * Backward accumulates (atomically) into dword [V,H], dpos [P,H], dtype [2,H], dgamma, dbeta (fp32, pre-zeroed). */
-int mmsim_embed_ln_fwd(const long long* ids, const long long* token_types, const float* word, const float* pos,
-                       const float* type, const float* gamma, const float* beta, void* out, int B, int S, int H,
-                       float eps, float dropout_p, unsigned long long seed, unsigned int stream_id, void* stream);
-int mmsim_embed_ln_bwd(const void* dout, const long long* ids, const long long* token_types, const float* word,
-                       const float* pos, const float* type, const float* gamma, float* dword, float* dpos,
-                       float* dtype, float* dgamma, float* dbeta, int B, int S, int H, float eps, float dropout_p,
+int mmsim_embed_ln_fwd(const long long* ids, const long long* token_types, const long long* position_ids,
+                       const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
+                       void* out, int B, int S, int H, int vocab_size, int type_vocab_size, int max_positions,
+                       int* err_flag, float eps, float dropout_p, unsigned long long seed, unsigned int stream_id,
+                       void* stream);
+int mmsim_embed_ln_bwd(const void* dout, const long long* ids, const long long* token_types, const long long* position_ids,
+                       const float* word, const float* pos, const float* type, const float* gamma, float* dword,
+                       float* dpos, float* dtype, float* dgamma, float* dbeta, int B, int S, int H, int vocab_size,
+                       int type_vocab_size, int max_positions, int* err_flag, float eps, float dropout_p,
                        unsigned long long seed, unsigned int stream_id, void* stream);
 
 /* ---- y = dropout(t) + resid ; h = LayerNorm(y)  (BertSelfOutput / BertOutput, modeling_bert.py:289-293, 347-351).

@@ -75,21 +75,24 @@ class MultimodalClassifier(nn.Module):
                 with torch.cuda.stream(side):
                     img_embedding = self.cv.predict_emb(img_input)
             elif defer or not torch.is_grad_enabled():
-                if defer:
-                    backbone.defer_launches()
-                    try:
+                # the whole defer -> text tower -> flush sequence is one unit: if anything in it raises (CPU ids, S beyond the
+                # position table, MmsimError), the tower must not stay armed -- a later standalone forward would otherwise
+                # return an unwritten tensor
+                try:
+                    if defer:
+                        backbone.defer_launches()
                         with torch.cuda.stream(side):
                             img_embedding = self.cv.predict_emb(img_input)          # autograd node only
-                    except BaseException:
-                        backbone._defer = None
-                        raise
-                title_embedding = self.nlp.predict_emb(query_input_ids=query_input_ids, query_token_type_ids=query_token_type_ids,
-                                                       query_attention_mask=query_attention_mask)
-                with torch.cuda.stream(side):
+                    title_embedding = self.nlp.predict_emb(query_input_ids=query_input_ids, query_token_type_ids=query_token_type_ids,
+                                                           query_attention_mask=query_attention_mask)
+                    with torch.cuda.stream(side):
+                        if defer:
+                            backbone.flush_deferred()
+                        else:
+                            img_embedding = self.cv.predict_emb(img_input)
+                finally:
                     if defer:
-                        backbone.flush_deferred()
-                    else:
-                        img_embedding = self.cv.predict_emb(img_input)
+                        backbone._defer = None
             else:
                 with torch.cuda.stream(side):
                     img_embedding = self.cv.predict_emb(img_input)

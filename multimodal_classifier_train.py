@@ -69,6 +69,8 @@ def main(argv=None):
     ap.add_argument("--max-steps", type=int, default=None)
     args = ap.parse_args(argv)
 
+    # before the first HIP call of the process: the host driver only supports dmabuf IPC (RCCL / cross-process tensors)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
@@ -120,9 +122,9 @@ def main(argv=None):
 
     global_step, test_acc, t_last = 0, 0.0, time.time()
     for epoch in range(args.num_epochs):
-        data_iter = iter(loaders[0]) if loaders else None
         if loaders and world > 1:
-            loaders[0].sampler.set_epoch(epoch)
+            loaders[0].sampler.set_epoch(epoch)       # before the iterator draws its indices, or the epoch's shuffle lags by one
+        data_iter = iter(loaders[0]) if loaders else None
         for it in range(args.steps_per_epoch):
             if data_iter is not None:
                 batch = finish_batch(next(data_iter), transform_eff, device)

@@ -108,6 +108,7 @@ class _Workspace:
         self.y2 = [e(M, H) for _ in range(n)]
         self.lse = [e(B * nh * S, dt=f32) for _ in range(n)]
         self.st = [e(4, M, dt=f32) for _ in range(n)]     # mean1, rstd1, mean2, rstd2
+        self.gen = 0          # bumped by every forward that writes this workspace; an autograd context remembers its value
         self.t = e(M, H)
         self.cls = e(B, H)
         self.pooled = e(B, H, dt=f32)
@@ -175,6 +176,7 @@ class BertModel(nn.Module):
         self._anchor = fn(self._anchor.detach()).requires_grad_(True)
         self._rebind()
         self._ws = {}
+        self.__dict__.pop("_err", None)
         return self
 
     def _bind_grads(self):
@@ -200,22 +202,43 @@ class BertModel(nn.Module):
         st = self.__dict__.copy()
         st["_ws"] = {}
         st["grad_ready_hook"] = None
+        st.pop("_err", None)
         return st
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, **_):
-        if position_ids is not None:
-            raise NotImplementedError("position_ids other than None (= arange(S)) are not supported; the reference "
-                                      "never supplies them (multimodal_classifier.py:35-38 drops them)")
+        """HF BertModel.forward (modeling_bert.py:623-686) -> namespace with ``pooler_output``.  ``position_ids`` ([B,S], [1,S] or
+        [S]; None = arange(S)) are forwarded as nlp_classifier.py:23-27 / transformer_emb.py:20-24 forward them."""
         if not input_ids.is_cuda:
             raise MmsimError("BertModel.forward: inputs must be on the GPU; the HIP path has no CPU fallback")
+        if position_ids is not None:
+            if position_ids.dim() == 1:
+                position_ids = position_ids.unsqueeze(0)
+            position_ids = position_ids.to(device=input_ids.device, dtype=torch.long).expand(input_ids.shape).contiguous()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if need_grad:
-            pooled = _BertFn.apply(self._anchor, self, input_ids, token_type_ids, attention_mask)
+            pooled = _BertFn.apply(self._anchor, self, input_ids, token_type_ids, attention_mask, position_ids)
         else:
-            ws = self._run_forward(input_ids, token_type_ids, attention_mask, keep=False)
+            ws = self._run_forward(input_ids, token_type_ids, attention_mask, keep=False, pids=position_ids)
             pooled = ws.pooled.clone()
         return SimpleNamespace(pooler_output=pooled, last_hidden_state=None)
+
+    def _err_flag(self):
+        f = self.__dict__.get("_err")
+        dev = self._flat.master.device
+        if f is None or f.device != dev:
+            f = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.__dict__["_err"] = f
+            ops.register_error_flag(f, IndexError, "BertModel: a token / token-type / position index was outside its embedding table")
+        return f
+
+    def check_indices(self):
+        """Raise IndexError if any forward since the last check saw an index outside its embedding table (nn.Embedding raises
+        eagerly; here the kernels clamp the index and raise a device flag, read on request: one host sync)."""
+        f = self.__dict__.get("_err")
+        if f is not None and f.is_cuda and int(f.item()) != 0:
+            f.zero_()
+            raise IndexError("BertModel: a token / token-type / position index was outside its embedding table")
 
     def _workspace(self, B, S, keep):
         key = (B, S, keep)
@@ -225,16 +248,17 @@ class BertModel(nn.Module):
             self._ws[key] = ws
         return ws
 
-    def _run_forward(self, ids, tts, mask, keep):
+    def _run_forward(self, ids, tts, mask, keep, pids=None):
         cfg, fl = self.config, self._flat
         if ids.dim() != 2:
             raise ValueError("input_ids must be [B, S]")
         B, S = ids.shape
         H, L, nh = cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads
-        if S > cfg.max_position_embeddings:
+        if pids is None and S > cfg.max_position_embeddings:
             raise ValueError("sequence longer than max_position_embeddings")
         fl.sync_shadow()
         ws = self._workspace(B, S, keep)
+        ws.gen += 1
         train = self.training
         ph = cfg.hidden_dropout_prob if train else 0.0
         pa = cfg.attention_probs_dropout_prob if train else 0.0
@@ -244,11 +268,12 @@ class BertModel(nn.Module):
         ids = ids.contiguous()
         tts = tts.contiguous() if tts is not None else None
         mask = mask.contiguous() if mask is not None else None
-        ws.meta = SimpleNamespace(B=B, S=S, ids=ids, tts=tts, mask=mask, ph=ph, pa=pa, seed=seed)
+        ws.meta = SimpleNamespace(B=B, S=S, ids=ids, tts=tts, mask=mask, ph=ph, pa=pa, seed=seed, pids=pids)
         V = fl.view
         ops.embed_ln_fwd(ids, tts, V("embeddings.word_embeddings.weight"), V("embeddings.position_embeddings.weight"),
                          V("embeddings.token_type_embeddings.weight"), V("embeddings.LayerNorm.weight"),
-                         V("embeddings.LayerNorm.bias"), ws.h[0], B, S, H, cfg.layer_norm_eps, ph, seed, 0)
+                         V("embeddings.LayerNorm.bias"), ws.h[0], B, S, H, cfg.layer_norm_eps, self._err_flag(), ph, seed, 0,
+                         pids=pids)
         I = cfg.intermediate_size
         for li in range(L):
             k = li if keep else 0
@@ -347,22 +372,28 @@ class BertModel(nn.Module):
                          V("embeddings.token_type_embeddings.weight"), V("embeddings.LayerNorm.weight"),
                          G("embeddings.word_embeddings.weight"), G("embeddings.position_embeddings.weight"),
                          G("embeddings.token_type_embeddings.weight"), G("embeddings.LayerNorm.weight"),
-                         G("embeddings.LayerNorm.bias"), B, S, H, cfg.layer_norm_eps, m.ph, m.seed, 0)
+                         G("embeddings.LayerNorm.bias"), B, S, H, cfg.layer_norm_eps, self._err_flag(), m.ph, m.seed, 0,
+                         pids=m.pids)
         if self.grad_ready_hook:
             self.grad_ready_hook(fl, *fl.span("embeddings.word_embeddings.weight", "embeddings.LayerNorm.bias"))
 
 
 class _BertFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, model, ids, tts, mask):
-        ws = model._run_forward(ids, tts, mask, keep=True)
-        ctx.model, ctx.ws = model, ws
+    def forward(ctx, anchor, model, ids, tts, mask, pids=None):
+        ws = model._run_forward(ids, tts, mask, keep=True, pids=pids)
+        ctx.model, ctx.ws, ctx.gen = model, ws, ws.gen
         return ws.pooled.clone()
 
     @staticmethod
     def backward(ctx, dpooled):
+        # the saved activations live in the module's per-(B, S) workspace, which the next grad-enabled forward of the same
+        # shape overwrites: backward of an older forward would silently use the newer activations
+        if ctx.ws.gen != ctx.gen:
+            raise MmsimError("BertModel: backward of a forward whose activation workspace has been overwritten by a later "
+                             "forward of the same (B, S); run backward before the next grad-enabled forward of this shape")
         ctx.model._run_backward(ctx.ws, dpooled)
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 def as_native(ptm):

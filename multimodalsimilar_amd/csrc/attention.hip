@@ -433,10 +433,11 @@ static int attn_bwd_impl(const void* qkv, int ld_qkv, const long long* mask, con
   const int NT = S / 32;
   const size_t lds = attn_bwd_lds(S);
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_done = false;
-  if (!attr_done) {   // S = 128 needs 48 KiB of dynamic LDS
+  static unsigned long long attr_done = 0;          // per device
+  const int dev = mmsim_current_device();
+  if (!((attr_done >> dev) & 1)) {   // S = 128 needs 48 KiB of dynamic LDS
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_bwd_lds(128));
-    attr_done = true;
+    attr_done |= 1ull << dev;
   }
   dim3 grid(B * heads), block(64 * NT);
   if (NT == 1) hipLaunchKernelGGL((attn_bwd_kernel<1>), grid, block, lds, s, p);

@@ -19,6 +19,7 @@ typedef __attribute__((ext_vector_type(8))) short s8;
 
 extern "C" void mmsim_set_error(const char* msg);
 int mmsim_check_launch(const char* what);
+int mmsim_current_device(void);
 
 #define MMSIM_REQUIRE(cond, msg)                 \
   do {                                           \

@@ -22,7 +22,14 @@ int mmsim_check_launch(const char* what) {
   return MMSIM_OK;
 }
 
-extern "C" int mmsim_version(void) { return 100; }
+// Device of the calling thread (0..63), for per-device one-time setup such as hipFuncSetAttribute opt-ins.
+int mmsim_current_device(void) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) d = 0;
+  return d;
+}
+
+extern "C" int mmsim_version(void) { return 200; }
 
 // Returns the number of visible HIP devices, or -1 with the error string set.
 extern "C" int mmsim_device_count(void) {

@@ -275,7 +275,11 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   p.xf_scale = xf_scale; p.xf_shift = xf_shift; p.xf_gate = xf_gate; p.xf_hw = xf_hw > 0 ? xf_hw : 1; p.xf_dhw = make_fastdiv(p.xf_hw);
   p.xf_C = (xf_operand == 1) ? K : N;
   p.stats = stats; p.band = 1;
+#ifdef MMSIM_ABLATE     // ablation object only (tools/bench_gemm_abl.py); the product library never reads this variable
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MMSIM_GEMM_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+#else
+  p.dbg = 0;
+#endif
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
   int kps = (K + split_k - 1) / split_k;
   kps = ((kps + BK - 1) / BK) * BK;
@@ -289,15 +293,16 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
     gemm_fast_launch(p, trans_a, b_kmajor, splits, s);
     return mmsim_check_launch("gemm_bf16_fast");
   }
-  static bool attr_done = false;
-  if (!attr_done) {   // 80 KiB of dynamic LDS per block needs the opt-in on every instantiation
+  static unsigned long long attr_done = 0;          // per device
+  const int dev = mmsim_current_device();
+  if (!((attr_done >> dev) & 1)) {   // 80 KiB of dynamic LDS per block needs the opt-in on every instantiation
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+    attr_done |= 1ull << dev;
   }
   if (xf_operand == 1) {
     hipLaunchKernelGGL((gemm_bf16_kernel<false, true, 1>), grid, block, lds, s, p);

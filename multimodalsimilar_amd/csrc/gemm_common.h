@@ -15,7 +15,7 @@ struct GemmParams {
   // >= tiles_m1 belong to it (A2 / B2 / C2).  Used to run the attention-output and the q|k|v weight gradients of a layer as
   // one 256-block launch (16 + 48 output tiles x 4 splits) instead of two launches that each under-fill the chip.
   const bf16* A2; const bf16* B2; void* C2; int lda2, ldb2, ldc2, tiles_m1;
-  int dbg;   // ablation switches for tools/bench_gemm.py (MMSIM_GEMM_DBG): 1 no DMA, 2 no LDS reads, 4 no MFMA; 0 in production
+  int dbg;   // ablation object only (-DMMSIM_ABLATE): 1 no DMA, 4 no MFMA, 8 no epilogue; the product build ignores it
 };
 
 // EPI_ROWFIX: C[m][n] (+)= r[m] * (acc - aux_in[m][n] * r[M + m]) with the two fp32 row vectors r passed in `bias` ([2][M]):

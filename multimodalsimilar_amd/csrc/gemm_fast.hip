@@ -174,6 +174,14 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p) {
 
 #define GBM 256
 
+// Main-loop ablation switches (no DMA / no MFMA / no epilogue) exist ONLY in the separately compiled ablation object
+// (-DMMSIM_ABLATE, tools/bench_gemm_abl.py builds it next to the product library): the product binary has no such code path.
+#ifdef MMSIM_ABLATE
+#define PP64_DBG(p) ((p).dbg)
+#else
+#define PP64_DBG(p) 0
+#endif
+
 // ---------------------------------------------------------------------------------------------------------
 // Ping-pong kernel with 64-deep K-slices (the production path for tile-aligned products).
 // 256 x BN output tiles, 8 waves (BN = 256: 2 x 4 waves of 128 x 64; BN = 128: 4 x 2 waves of 64 x 64), operands by
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-  const bool dma_on = !(p.dbg & 1);
+  const bool dma_on = !(PP64_DBG(p) & 1);
   if (dma_on) {
     dma_tile<TA, GBM>(gA, glda, m0, kbeg, smem, wave, lane);
     dma_tile<!TB_KMAJOR, BN>(gB, gldb, n0, kbeg, smem + B_OFF, wave, lane);
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
 #define PP64_MFMA()                                                                                      \
   __builtin_amdgcn_s_barrier();                                                                          \
   __builtin_amdgcn_sched_barrier(0);                                                                     \
-  if (!(p.dbg & 4)) {                                                                                    \
+  if (!(PP64_DBG(p) & 4)) {                                                                                   \
     /* no s_setprio around the MFMAs: measured 1 % slower with it on this schedule (the partner wave is in its load phase) */ \
     _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                       \
       _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
   if (grp == 0) __builtin_amdgcn_s_barrier();            // both groups have now executed 4 ns + 1 barriers
   const bool fs = split == 0;
   float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
-  if (p.dbg & 8) {
+  if (PP64_DBG(p) & 8) {
     float sacc = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -359,13 +367,14 @@ static void launch_pipe(GemmParams p, int trans_a, int b_kmajor, int splits, hip
   // 160 KiB: A ring 3 x 32 KiB + B ring 2 x (BN x 128 B); never less than the epilogue staging (8 waves x 64 x 68 floats)
   const size_t lds_stage = 8 * 64 * EP_PITCH * 4, lds_ring = 3 * GBM * 128 + 2 * BN * 128;
   const size_t lds = lds_ring > lds_stage ? lds_ring : lds_stage;
-  static bool done = false;
-  if (!done) {
+  static unsigned long long done = 0;          // per device: the opt-in is a property of (function, device)
+  const int dev = mmsim_current_device();
+  if (!((done >> dev) & 1)) {
     (void)hipFuncSetAttribute((const void*)gemm_pp64_kernel<false, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_pp64_kernel<false, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_pp64_kernel<true, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_pp64_kernel<true, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    done = true;
+    done |= 1ull << dev;
   }
   {
     static int band = -1;            // MMSIM_GEMM_BAND: tile-rows per band of the tile walk (1 = row-major)
@@ -403,13 +412,14 @@ void gemm_fast_launch(GemmParams p, int trans_a, int b_kmajor, int splits, hipSt
   p.splits = splits;
   dim3 grid(p.tiles_m * p.tiles_n * splits), block(512);
   const size_t lds = 3 * F_STAGE;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;
+  const int dev = mmsim_current_device();
+  if (!((attr_done >> dev) & 1)) {
     (void)hipFuncSetAttribute((const void*)gemm_fast_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_fast_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_fast_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_fast_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+    attr_done |= 1ull << dev;
   }
   if (!trans_a && b_kmajor) hipLaunchKernelGGL((gemm_fast_kernel<false, true>), grid, block, lds, s, p);
   else if (!trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_fast_kernel<false, false>), grid, block, lds, s, p);
@@ -443,10 +453,11 @@ extern "C" int mmsim_gemm_bf16_wgrad_pair(int M1, int M2, int N, int K, const vo
   { const char* e = getenv("MMSIM_GEMM_BAND"); p.band = e ? atoi(e) : 8; if (p.band < 1) p.band = 1; }
   const size_t lds_stage = 8 * 64 * EP_PITCH * 4, lds_ring = 3 * GBM * 128 + 2 * 256 * 128;
   const size_t lds = lds_ring > lds_stage ? lds_ring : lds_stage;
-  static bool done = false;
-  if (!done) {
+  static unsigned long long done = 0;
+  const int dev = mmsim_current_device();
+  if (!((done >> dev) & 1)) {
     (void)hipFuncSetAttribute((const void*)gemm_pp64_kernel<true, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    done = true;
+    done |= 1ull << dev;
   }
   hipLaunchKernelGGL((gemm_pp64_kernel<true, false, 256, true>), dim3(p.tiles_m * p.tiles_n * splits), dim3(512), lds, (hipStream_t)stream, p);
   return mmsim_check_launch("gemm_wgrad_pair");

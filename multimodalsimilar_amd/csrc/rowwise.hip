@@ -56,15 +56,33 @@ __device__ __forceinline__ void row_stats(const float4 (&v)[MAXC], int nc, int H
 }
 
 // ---------------------------------------------------------------- embeddings + LayerNorm
-__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, const int64_t* tts, const float* word,
+// Token / token-type / position indices index tables: an index outside its table raises the device error flag (read by the
+// host where it reads the head's label flag) and is clamped, so that neither the gather nor the backward's scatter-add
+// leaves its table (HF: nn.Embedding raises an IndexError).
+struct EmbedIdx { int64_t id, tt, s; };
+__device__ __forceinline__ EmbedIdx embed_idx(const int64_t* ids, const int64_t* tts, const int64_t* pids, int row, int S, int vocab,
+                                              int tvocab, int max_pos, int* err) {
+  EmbedIdx e;
+  e.id = ids[row]; e.tt = tts ? tts[row] : 0; e.s = pids ? pids[row] : (int64_t)(row % S);
+  const bool bad = e.id < 0 || e.id >= vocab || e.tt < 0 || e.tt >= tvocab || e.s < 0 || e.s >= max_pos;
+  if (bad) {
+    if ((threadIdx.x & 63) == 0) atomicOr(err, 1);
+    e.id = e.id < 0 ? 0 : (e.id >= vocab ? vocab - 1 : e.id);
+    e.tt = e.tt < 0 ? 0 : (e.tt >= tvocab ? tvocab - 1 : e.tt);
+    e.s = e.s < 0 ? 0 : (e.s >= max_pos ? max_pos - 1 : e.s);
+  }
+  return e;
+}
+
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, const int64_t* tts, const int64_t* pids, const float* word,
                                                            const float* pos, const float* type, const float* gamma,
                                                            const float* beta, bf16* out, int M, int S, int H, float eps,
-                                                           Drop dr) {
+                                                           Drop dr, int vocab, int tvocab, int max_pos, int* err) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wv;
   if (row >= M) return;
-  const int64_t id = ids[row], tt = tts ? tts[row] : 0;
-  const int s = row % S;
+  const EmbedIdx ei = embed_idx(ids, tts, pids, row, S, vocab, tvocab, max_pos, err);
+  const int64_t id = ei.id, tt = ei.tt, s = ei.s;
   float4 v[MAXC];
   int nc = 0;
 #pragma unroll
@@ -93,23 +111,24 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* ids, c
 
 // backward of the embedding block.  Each wave owns one position s and a chunk of the batch, so the
 // position/type/gamma/beta gradients accumulate in registers and leave as one atomic row per wave.
-__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* dout, const int64_t* ids, const int64_t* tts,
+__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* dout, const int64_t* ids, const int64_t* tts, const int64_t* pids,
                                                            const float* word, const float* pos, const float* type,
                                                            const float* gamma, float* dword, float* dpos, float* dtype,
                                                            float* dgamma, float* dbeta, int B, int S, int H, float eps,
-                                                           int bchunk, Drop dr) {
+                                                           int bchunk, Drop dr, int vocab, int tvocab, int max_pos, int* err) {
   __shared__ __attribute__((aligned(16))) float rowbuf[4][MAXC * 256];       // one d(embedding) row per wave
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int gw = blockIdx.x * 4 + wv;
   const int nchunks = (B + bchunk - 1) / bchunk;
   if (gw >= S * nchunks) return;
-  const int s = gw % S, b0 = (gw / S) * bchunk, b1 = min(B, b0 + bchunk);
+  const int sw = gw % S, b0 = (gw / S) * bchunk, b1 = min(B, b0 + bchunk);
   float4 apos[MAXC], at0[MAXC], at1[MAXC], ag[MAXC], ab[MAXC];
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) apos[c] = at0[c] = at1[c] = ag[c] = ab[c] = make_float4(0, 0, 0, 0);
   for (int b = b0; b < b1; ++b) {
-    const int row = b * S + s;
-    const int64_t id = ids[row], tt = tts ? tts[row] : 0;
+    const int row = b * S + sw;
+    const EmbedIdx ei = embed_idx(ids, tts, pids, row, S, vocab, tvocab, max_pos, err);
+    const int64_t id = ei.id, tt = ei.tt, s = ei.s;      // s == sw unless explicit position ids were given
     float4 v[MAXC], g[MAXC];
     int nc = 0;
 #pragma unroll
@@ -163,6 +182,14 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* dout, con
       const int col = j * 64 + lane;
       if (col < H) atomicAdd(dw + col, rowbuf[wv][col]);
     }
+    if (pids) {      // explicit position ids: the position row differs from row to row, scatter-add it like the word row
+      float* dp = dpos + (size_t)s * H;
+#pragma unroll
+      for (int j = 0; j < MAXC * 4; ++j) {
+        const int col = j * 64 + lane;
+        if (col < H) atomicAdd(dp + col, rowbuf[wv][col]);
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -170,8 +197,8 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* dout, con
   for (int c = 0; c < MAXC; ++c) {
     const int col = lane * 4 + c * 256;
     if (col < H) {
-      float* a = dpos + (size_t)s * H + col;
-      atomicAdd(a, apos[c].x); atomicAdd(a + 1, apos[c].y); atomicAdd(a + 2, apos[c].z); atomicAdd(a + 3, apos[c].w);
+      float* a = dpos + (size_t)sw * H + col;
+      if (!pids) { atomicAdd(a, apos[c].x); atomicAdd(a + 1, apos[c].y); atomicAdd(a + 2, apos[c].z); atomicAdd(a + 3, apos[c].w); }
       a = dtype + col;
       atomicAdd(a, at0[c].x); atomicAdd(a + 1, at0[c].y); atomicAdd(a + 2, at0[c].z); atomicAdd(a + 3, at0[c].w);
       a = dtype + H + col;
@@ -521,29 +548,37 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const TX* x, int ldx, c
 // ================================================================= C-ABI
 #define ROWS_GRID(M) dim3(((M) + 3) / 4)
 
-extern "C" int mmsim_embed_ln_fwd(const long long* ids, const long long* token_types, const float* word, const float* pos,
-                                  const float* type, const float* gamma, const float* beta, void* out, int B, int S, int H,
-                                  float eps, float dropout_p, unsigned long long seed, unsigned int stream_id, void* stream) {
-  MMSIM_REQUIRE(ids && word && pos && type && gamma && beta && out, "embed_ln_fwd: null operand");
+extern "C" int mmsim_embed_ln_fwd(const long long* ids, const long long* token_types, const long long* position_ids,
+                                  const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
+                                  void* out, int B, int S, int H, int vocab_size, int type_vocab_size, int max_positions,
+                                  int* err_flag, float eps, float dropout_p, unsigned long long seed, unsigned int stream_id,
+                                  void* stream) {
+  MMSIM_REQUIRE(ids && word && pos && type && gamma && beta && out && err_flag, "embed_ln_fwd: null operand");
   MMSIM_REQUIRE(H % 4 == 0 && H <= 256 * MAXC, "embed_ln_fwd: H must be a multiple of 4 and <= 2048");
+  MMSIM_REQUIRE(vocab_size > 0 && type_vocab_size > 0 && max_positions > 0, "embed_ln_fwd: table sizes must be positive");
+  MMSIM_REQUIRE(position_ids || S <= max_positions, "embed_ln_fwd: S exceeds the position table");
   const int M = B * S;
   hipLaunchKernelGGL(embed_ln_fwd_kernel, ROWS_GRID(M), dim3(256), 0, (hipStream_t)stream, (const int64_t*)ids,
-                     (const int64_t*)token_types, word, pos, type, gamma, beta, (bf16*)out, M, S, H, eps,
-                     make_drop(dropout_p, seed, stream_id));
+                     (const int64_t*)token_types, (const int64_t*)position_ids, word, pos, type, gamma, beta, (bf16*)out, M, S, H, eps,
+                     make_drop(dropout_p, seed, stream_id), vocab_size, type_vocab_size, max_positions, err_flag);
   return mmsim_check_launch("embed_ln_fwd");
 }
 
-extern "C" int mmsim_embed_ln_bwd(const void* dout, const long long* ids, const long long* token_types, const float* word,
-                                  const float* pos, const float* type, const float* gamma, float* dword, float* dpos,
-                                  float* dtype, float* dgamma, float* dbeta, int B, int S, int H, float eps, float dropout_p,
+extern "C" int mmsim_embed_ln_bwd(const void* dout, const long long* ids, const long long* token_types, const long long* position_ids,
+                                  const float* word, const float* pos, const float* type, const float* gamma, float* dword,
+                                  float* dpos, float* dtype, float* dgamma, float* dbeta, int B, int S, int H, int vocab_size,
+                                  int type_vocab_size, int max_positions, int* err_flag, float eps, float dropout_p,
                                   unsigned long long seed, unsigned int stream_id, void* stream) {
-  MMSIM_REQUIRE(dout && ids && word && dword && dpos && dtype && dgamma && dbeta, "embed_ln_bwd: null operand");
+  MMSIM_REQUIRE(dout && ids && word && dword && dpos && dtype && dgamma && dbeta && err_flag, "embed_ln_bwd: null operand");
   MMSIM_REQUIRE(H % 4 == 0 && H <= 256 * MAXC, "embed_ln_bwd: H must be a multiple of 4 and <= 2048");
+  MMSIM_REQUIRE(vocab_size > 0 && type_vocab_size > 0 && type_vocab_size <= 2 && max_positions > 0,
+                "embed_ln_bwd: table sizes must be positive (at most two token types)");
   const int bchunk = B >= 64 ? 16 : (B >= 8 ? 4 : 1);
   const int nw = S * ((B + bchunk - 1) / bchunk);
   hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout,
-                     (const int64_t*)ids, (const int64_t*)token_types, word, pos, type, gamma, dword, dpos, dtype, dgamma,
-                     dbeta, B, S, H, eps, bchunk, make_drop(dropout_p, seed, stream_id));
+                     (const int64_t*)ids, (const int64_t*)token_types, (const int64_t*)position_ids, word, pos, type, gamma, dword, dpos,
+                     dtype, dgamma, dbeta, B, S, H, eps, bchunk, make_drop(dropout_p, seed, stream_id), vocab_size, type_vocab_size,
+                     max_positions, err_flag);
   return mmsim_check_launch("embed_ln_bwd");
 }
 

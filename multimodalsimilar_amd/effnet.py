@@ -244,7 +244,11 @@ class EfficientNet(nn.Module):
         self._defer = []
 
     def flush_deferred(self):
-        pend, self._defer = self._defer or [], None
+        if self._defer is None:
+            raise MmsimError("EfficientNet.flush_deferred() without defer_launches()")
+        pend, self._defer = self._defer, None
+        if len(pend) > 1:
+            raise MmsimError("EfficientNet: more than one deferred forward (their BatchNorm scratch would alias)")
         with torch.no_grad():          # `out` already carries the node: an in-place write under grad mode would rebase its history
             for x, out, holder in pend:
                 holder.st = self._run_forward(x)
@@ -357,7 +361,8 @@ class EfficientNet(nn.Module):
         dev = x.device
         bf = torch.bfloat16
         self._step_seed += 1
-        st = SimpleNamespace(B=B, Hi=Hi, Wi=Wi, x=x, blocks=[])
+        self._gen = getattr(self, "_gen", 0) + 1      # BN statistics live in module scratch (bnstat): see _run_backward
+        st = SimpleNamespace(B=B, Hi=Hi, Wi=Wi, x=x, blocks=[], gen=self._gen)
         st.bnstat = self._buf("bnstat", (4, self._bn_total), torch.float32)
         st.sums_f = self._buf("sums_f", (2 * self._bn_total,), torch.float32)
         st.sums_f.zero_()
@@ -487,6 +492,9 @@ class EfficientNet(nn.Module):
 
     def _run_backward(self, st, dpooled):
         a, fl = self.arch, self._flat
+        if st.gen != getattr(self, "_gen", 0):
+            raise MmsimError("EfficientNet: backward of a forward whose BatchNorm statistics scratch was overwritten by a later "
+                             "forward; run backward before the next forward of this tower")
         self._bind_grads()
         s = ops._stream()
         B = st.B

@@ -45,6 +45,7 @@ class ArcMarginProduct(nn.Module):
         self.cos_m, self.sin_m, self.th, self.mm = _margin_consts(m)                 # arcface.py:28-33
         self._scratch = {}
         self._wh_key = None           # (weight version, address) the cached F.normalize(weight) belongs to
+        self._gen = 0                 # bumped by every _cosines(): autograd contexts check their scratch is still theirs
         self.grad_ready_hook = None
 
     def update_m(self, delta):                                                       # arcface.py:35-42
@@ -116,13 +117,21 @@ class ArcMarginProduct(nn.Module):
         xh = self._buf("xh", (B, D), torch.bfloat16)
         inv_x = self._buf("inv_x", (B,), torch.float32)
         cos = self._buf("cos", (B, ldc), torch.float32, zero=True)
+        self._gen = getattr(self, "_gen", 0) + 1
         key = (self.weight._version, self.weight.data_ptr())
         if self._wh_key != key:               # otherwise w_hat is current: left by the last AdamW launch, or the weights are static
             ops.l2norm_fwd(self.weight.detach(), None, wh, 0, inv_w)                 # F.normalize(self.weight)
             self._wh_key = key
         ops.l2norm_fwd(x, None, xh, 0, inv_x)                                        # F.normalize(x)
         ops.gemm(xh, wh, cos[:, :C])                                                 # F.linear  (arcface.py:47)
-        return cos, dict(x=x, xh=xh, wh=wh, inv_x=inv_x, inv_w=inv_w, B=B, ldc=ldc)
+        return cos, dict(x=x, xh=xh, wh=wh, inv_x=inv_x, inv_w=inv_w, B=B, ldc=ldc, gen=self._gen)
+
+    def _check_gen(self, st):
+        # xh / inv_x / cos / dcos are module scratch reused by the next call: a backward that runs after another forward
+        # would read the newer call's values
+        if st["gen"] != self._gen:
+            raise MmsimError("ArcMarginProduct: backward of a forward whose scratch buffers were overwritten by a later call; "
+                             "run backward before the next forward of this head")
 
     def _backward_from_dcos(self, st, dcos, cos=None):
         """dcos bf16 [B, ldc] (pad zero) -> dx f32 [B,D]; accumulates into weight.grad.  With the cosines at hand the backward of
@@ -152,14 +161,20 @@ class ArcMarginProduct(nn.Module):
         return dx
 
     def _err_flag(self):
-        return self._buf("err", (1,), torch.int32, zero=True)
+        new = ("err", (1,), torch.int32) not in self._scratch
+        f = self._buf("err", (1,), torch.int32, zero=True)
+        if new:
+            ops.register_error_flag(f, IndexError, "ArcMarginProduct: label out of range [0, out_feature)")
+        return f
 
     def check_labels(self):
-        """Raise if any label seen since the last check was outside [0, out_feature) (reference: scatter_ raises)."""
+        """Raise if any label seen since the last check was outside [0, out_feature) (reference: scatter_ raises); also reads
+        every other registered device error flag (token / position ids of the text tower feeding this head)."""
         f = self._scratch.get(("err", (1,), torch.int32))
         if f is not None and int(f.item()) != 0:
             f.zero_()
             raise IndexError("ArcMarginProduct: label out of range [0, out_feature)")
+        ops.check_device_flags()
 
     # ---- public API
     def forward(self, x, label):                                                     # arcface.py:45-63
@@ -192,6 +207,7 @@ class _ArcLogitsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         mod, st = ctx.mod, ctx.st
+        mod._check_gen(st)
         C = mod.out_feature
         dlogits = dlogits.contiguous().float()
         dcos = mod._buf("dcos", (st["B"], st["ldc"]), torch.bfloat16)
@@ -221,8 +237,10 @@ class _ArcLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloss, _dargmax):
-        dcos = ctx.dcos
-        dcos.mul_(dloss.to(dcos.dtype))      # chain rule for a non-unit upstream gradient (bf16(1.0) is exact)
+        ctx.mod._check_gen(ctx.st)
+        # chain rule for a non-unit upstream gradient: out of place (a second backward through a retained graph must not
+        # rescale the saved dcos) with the fp32 scalar (bf16 tensor x fp32 0-dim tensor multiplies in fp32, rounds once)
+        dcos = torch.mul(ctx.dcos, dloss.float(), out=ctx.mod._buf("dcos_scaled", tuple(ctx.dcos.shape), torch.bfloat16))
         dx = ctx.mod._backward_from_dcos(ctx.st, dcos, ctx.cos)
         return dx, None, None, None
 

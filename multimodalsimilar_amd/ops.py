@@ -43,6 +43,33 @@ def join_side_streams():
             cur.wait_stream(s)
 
 
+# Device-side error flags (int32, set by kernels that validate indices: ArcFace labels, token / position / type ids).  They are
+# read -- one host sync each -- where the caller asks for it: ArcMarginProduct.check_labels(), BertModel.check_indices(),
+# check_device_flags() (all of them); the eager API path (module.forward) checks after every call like the reference raises.
+_FLAGS = []
+
+
+def register_error_flag(tensor, exc_type, message):
+    import weakref
+    _FLAGS.append((weakref.ref(tensor), exc_type, message))
+
+
+def check_device_flags():
+    live = []
+    err = None
+    for ref, exc_type, message in _FLAGS:
+        t = ref()
+        if t is None:
+            continue
+        live.append((ref, exc_type, message))
+        if err is None and t.is_cuda and int(t.item()) != 0:
+            t.zero_()
+            err = exc_type(message)
+    _FLAGS[:] = live
+    if err is not None:
+        raise err
+
+
 def _chk(t, dtype, name, dims=None):
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a tensor, got {type(t).__name__}")
@@ -188,25 +215,42 @@ def attn_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, heads, H, dropout_p=0.0, see
                  float(dropout_p), seed, stream_id, _stream())
 
 
-def embed_ln_fwd(ids, tts, word, pos, typ, gamma, beta, out, B, S, H, eps, dropout_p=0.0, seed=0, stream_id=0):
-    _chk(ids, I64, "embed.ids"); _chk(out, BF16, "embed.out", 2)
+def _embed_tables(ids, tts, pids, word, pos, typ, err, B, S, name):
+    _chk(ids, I64, name + ".ids")
+    for t, n in ((tts, "token_types"), (pids, "position_ids")):
+        if t is not None:
+            _chk(t, I64, f"{name}.{n}")
+            if t.numel() != B * S or not t.is_contiguous():
+                raise ValueError(f"{name}.{n}: must hold B*S contiguous indices")
+    if err.dtype != torch.int32 or not err.is_cuda:
+        raise TypeError(f"{name}.err: int32 device flag required")
+    if ids.numel() != B * S or not ids.is_contiguous():
+        raise ValueError(f"{name}: ids must hold B*S contiguous tokens")
+    if pids is None and pos.shape[0] < S:
+        raise ValueError(f"{name}: the position table must cover S")
+    if typ.shape[0] > 2:
+        raise ValueError(f"{name}: at most two token types are supported")
+    return word.shape[0], typ.shape[0], pos.shape[0]
+
+
+def embed_ln_fwd(ids, tts, word, pos, typ, gamma, beta, out, B, S, H, eps, err, dropout_p=0.0, seed=0, stream_id=0, pids=None):
+    _chk(out, BF16, "embed.out", 2)
     for t, n in ((word, "word"), (pos, "pos"), (typ, "type"), (gamma, "gamma"), (beta, "beta")):
         _chk(t, F32, "embed." + n)
-    if tts is not None:
-        _chk(tts, I64, "embed.token_types")
-    if ids.numel() != B * S or pos.shape[0] < S:
-        raise ValueError("embed_ln_fwd: ids must hold B*S tokens and the position table must cover S")
-    lib.embed_ln_fwd(_p(ids), _p(tts), _p(word), _p(pos), _p(typ), _p(gamma), _p(beta), _p(out), B, S, H, eps,
-                     float(dropout_p), seed, stream_id, _stream())
+    V, TV, P = _embed_tables(ids, tts, pids, word, pos, typ, err, B, S, "embed")
+    lib.embed_ln_fwd(_p(ids), _p(tts), _p(pids), _p(word), _p(pos), _p(typ), _p(gamma), _p(beta), _p(out), B, S, H, V, TV, P,
+                     _p(err), eps, float(dropout_p), seed, stream_id, _stream())
 
 
-def embed_ln_bwd(dout, ids, tts, word, pos, typ, gamma, dword, dpos, dtype_, dgamma, dbeta, B, S, H, eps,
-                 dropout_p=0.0, seed=0, stream_id=0):
+def embed_ln_bwd(dout, ids, tts, word, pos, typ, gamma, dword, dpos, dtype_, dgamma, dbeta, B, S, H, eps, err,
+                 dropout_p=0.0, seed=0, stream_id=0, pids=None):
     _chk(dout, BF16, "embed_bwd.dout", 2)
     for t, n in ((dword, "dword"), (dpos, "dpos"), (dtype_, "dtype"), (dgamma, "dgamma"), (dbeta, "dbeta")):
         _chk(t, F32, "embed_bwd." + n)
-    lib.embed_ln_bwd(_p(dout), _p(ids), _p(tts), _p(word), _p(pos), _p(typ), _p(gamma), _p(dword), _p(dpos),
-                     _p(dtype_), _p(dgamma), _p(dbeta), B, S, H, eps, float(dropout_p), seed, stream_id, _stream())
+    V, TV, P = _embed_tables(ids, tts, pids, word, pos, typ, err, B, S, "embed_bwd")
+    lib.embed_ln_bwd(_p(dout), _p(ids), _p(tts), _p(pids), _p(word), _p(pos), _p(typ), _p(gamma), _p(dword), _p(dpos),
+                     _p(dtype_), _p(dgamma), _p(dbeta), B, S, H, V, TV, P, _p(err), eps, float(dropout_p), seed, stream_id,
+                     _stream())
 
 
 def add_ln_fwd(t, resid, gamma, beta, y, h, mean, rstd, eps, dropout_p=0.0, seed=0, stream_id=0):

@@ -146,10 +146,12 @@ class TrainStep:
         loss.backward()
         if self.exchange:
             self.exchange.finish()
+        # reference order (multimodal_classifier_train.py:195-201): BOTH optimisers step with lr(t); each schedule
+        # advances right after its own optimiser, so the head's first warm-up step runs at lr 0 and the last step at lr(T-1)
         self.opt_emb.step()
-        self.t += 1
-        self._set_lr()                          # lr_scheduler_*.step()
         self.opt_emb.zero_grad()
         self.opt_fc.step()
         self.opt_fc.zero_grad()
+        self.t += 1
+        self._set_lr()                          # lr_scheduler_emb.step(); lr_scheduler_fc.step()
         return loss.detach(), pred

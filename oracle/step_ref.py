@@ -46,10 +46,12 @@ class TwoTowerOracle:
         loss = arcface_ref.ce_loss(logits, batch["labels"])
         loss.backward()
         pred = logits.argmax(1)
+        # multimodal_classifier_train.py:195-201: optimizer_emb.step(); lr_scheduler_emb.step(); optimizer_fc.step();
+        # lr_scheduler_fc.step() -- both updates of step t use lr(t)
         self.opt_emb.step()
-        self.t += 1
-        self._set_lr()
         self.opt_emb.zero_grad()
         self.opt_fc.step()
         self.opt_fc.zero_grad()
+        self.t += 1
+        self._set_lr()
         return loss.detach(), pred

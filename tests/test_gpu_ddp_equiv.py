@@ -1,6 +1,6 @@
 """Data-parallel equivalence on the GPU box: two ranks (two processes sharing the one GPU, gloo rendezvous on
 127.0.0.1 -- RCCL refuses duplicate devices, the exchange code path is otherwise the same) each take half of a batch;
-after one step their parameters must equal a single process stepping on the whole batch: the update is the gradient of
+after two steps their parameters must equal a single process stepping on the whole batch: the update is the gradient of
 the GLOBAL-batch mean loss (reference semantics, nlp_classifier_train_daodian_v2_dist.py:139-144)."""
 import os
 import socket
@@ -32,9 +32,10 @@ def _worker(rank, world, port, out):
     model = T.build_model(CFG, "cuda", seed=0, dropout=False)
     ts = T.TrainStep(model, "nlp", 10)
     assert ts.exchange is not None and ts.exchange.world == 2
-    full = T.synthetic_batch(CFG, "cuda", seed=5)
-    half = {k: v[rank * 8:(rank + 1) * 8] for k, v in full.items()}
-    loss, _ = ts.step(half)
+    for i in range(2):      # two steps: the head's first warm-up step runs at lr 0 (reference order), the second one moves it
+        full = T.synthetic_batch(CFG, "cuda", seed=5 + i)
+        half = {k: v[rank * 8:(rank + 1) * 8] for k, v in full.items()}
+        loss, _ = ts.step(half)
     torch.cuda.synchronize()
     if rank == 0:
         torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, out)
@@ -50,7 +51,8 @@ def test_two_ranks_equal_one_process_on_the_whole_batch(tmp_path):
     model = T.build_model(CFG, "cuda", seed=0, dropout=False)
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     ts = T.TrainStep(model, "nlp", 10)
-    ts.step(T.synthetic_batch(CFG, "cuda", seed=5))
+    for i in range(2):
+        ts.step(T.synthetic_batch(CFG, "cuda", seed=5 + i))
     torch.cuda.synchronize()
     single = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     checked = 0

@@ -208,24 +208,72 @@ def test_hidden_dropout_mask_is_replayed_in_backward():
     assert relerr(dt.float()[keep], dy.float()[keep] / (1 - p)) < 1e-2
 
 
-def test_embed_ln_fwd_bwd():
+@pytest.mark.parametrize("with_pids", [False, True])
+def test_embed_ln_fwd_bwd(with_pids):
     ops = _ops()
     B, S, H, V = 5, 32, 256, 50
     word = rnd(V, H, seed=1, scale=0.5); pos = rnd(64, H, seed=2, scale=0.5); typ = rnd(2, H, seed=3, scale=0.5)
     gamma = 1 + 0.1 * rnd(H, seed=4); beta = 0.1 * rnd(H, seed=5)
     ids = torch.randint(0, V, (B, S), device=DEV); tts = torch.randint(0, 2, (B, S), device=DEV)
+    # explicit position ids (nlp_classifier.py:23-27 forwards them): arbitrary rows of the position table, repeated ones too
+    pids = torch.randint(0, 64, (B, S), device=DEV) if with_pids else None
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
     out = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV)
-    ops.embed_ln_fwd(ids, tts, word, pos, typ, gamma, beta, out, B, S, H, 1e-12)
+    ops.embed_ln_fwd(ids, tts, word, pos, typ, gamma, beta, out, B, S, H, 1e-12, err, pids=pids)
     ws = [t.clone().requires_grad_(True) for t in (word, pos, typ, gamma, beta)]
-    e = ws[0][ids] + ws[2][tts] + ws[1][torch.arange(S, device=DEV)].unsqueeze(0)
+    pe = ws[1][pids] if with_pids else ws[1][torch.arange(S, device=DEV)].unsqueeze(0)
+    e = ws[0][ids] + ws[2][tts] + pe
     ref = F.layer_norm(e, (H,), ws[3], ws[4], 1e-12).view(B * S, H)
     assert relerr(out, ref) < 1e-2
     dout = rnd(B * S, H, seed=6).bfloat16()
     ref.backward(dout.float())
     gs = [torch.zeros_like(t) for t in (word, pos, typ, gamma, beta)]
-    ops.embed_ln_bwd(dout, ids, tts, word, pos, typ, gamma, gs[0], gs[1], gs[2], gs[3], gs[4], B, S, H, 1e-12)
+    ops.embed_ln_bwd(dout, ids, tts, word, pos, typ, gamma, gs[0], gs[1], gs[2], gs[3], gs[4], B, S, H, 1e-12, err, pids=pids)
     for g, w, n in zip(gs, ws, ("word", "pos", "type", "gamma", "beta")):
         assert relerr(g, w.grad) < 2e-3, n
+    assert int(err.item()) == 0
+
+
+def test_embed_out_of_range_index_raises_flag_and_stays_inside_the_tables():
+    """A token id >= vocab (tokenizer / vocab mismatch) must neither read nor scatter-add outside the word table: the kernels
+    clamp it and raise the device flag (nn.Embedding raises an IndexError: BertModel.check_indices / check_labels read it)."""
+    ops = _ops()
+    B, S, H, V = 2, 32, 256, 50
+    word = rnd(V, H, seed=1, scale=0.5); pos = rnd(32, H, seed=2, scale=0.5); typ = rnd(2, H, seed=3, scale=0.5)
+    gamma = torch.ones(H, device=DEV); beta = torch.zeros(H, device=DEV)
+    ids = torch.randint(0, V, (B, S), device=DEV)
+    ids[1, 7] = V + 1000
+    ids[0, 3] = -5
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    out = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV)
+    ops.embed_ln_fwd(ids, None, word, pos, typ, gamma, beta, out, B, S, H, 1e-12, err)
+    assert int(err.item()) == 1 and torch.isfinite(out.float()).all()
+    # guard band after the word-gradient table: the scatter-add of the bad row must not land in it
+    buf = torch.zeros(V * H + 4096, device=DEV)
+    gs = [buf[:V * H].view(V, H), torch.zeros_like(pos), torch.zeros_like(typ), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)]
+    err.zero_()
+    ops.embed_ln_bwd(rnd(B * S, H, seed=6).bfloat16(), ids, None, word, pos, typ, gamma, *gs, B, S, H, 1e-12, err)
+    assert int(err.item()) == 1 and float(buf[V * H:].abs().max()) == 0.0
+
+
+def test_bert_forwards_position_ids_and_reports_bad_token_ids():
+    from multimodalsimilar_amd.bert import BertConfig, BertModel
+    cfg = BertConfig(vocab_size=64, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256,
+                     max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = BertModel(cfg, seed=0).to(DEV).eval()
+    ids = torch.randint(0, 64, (3, 32), device=DEV)
+    with torch.no_grad():
+        a = m(input_ids=ids).pooler_output
+        b = m(input_ids=ids, position_ids=torch.arange(32, device=DEV)).pooler_output          # the default, spelled out
+        c = m(input_ids=ids, position_ids=torch.arange(32, device=DEV).flip(0).unsqueeze(0)).pooler_output
+    assert torch.equal(a, b) and (a - c).abs().max() > 1e-3
+    m.check_indices()
+    bad = ids.clone(); bad[0, 0] = 64
+    with torch.no_grad():
+        m(input_ids=bad)
+    with pytest.raises(IndexError):
+        m.check_indices()
+    m.check_indices()          # the flag was cleared by the failed check
 
 
 def test_colsum_and_l2norm():

@@ -1,5 +1,15 @@
-"""Ablation of the 256x256x32 GEMM main loop (GPU box): MMSIM_GEMM_DBG bits 1 = no DMA, 4 = no MFMA, 8 = no epilogue."""
+"""Ablation of the pipelined GEMM main loop (GPU box): MMSIM_GEMM_DBG bits 1 = no DMA, 4 = no MFMA, 8 = no epilogue.
+The switches are compiled only into a SEPARATE ablation library (-DMMSIM_ABLATE, built here into gpurun_out/); the product
+library multimodalsimilar_amd/libmmsim_hip.so has no such code path and never reads the variable."""
 import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from multimodalsimilar_amd import build as _b
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+ABL = os.path.join(ROOT, "gpurun_out", "libmmsim_hip_ablate.so")
+srcs = [os.path.join(_b.CSRC, f) for f in _b.SOURCES]
+subprocess.check_call([_b.HIPCC] + _b.FLAGS + ["-DMMSIM_ABLATE", "-shared", "-o", ABL] + srcs)
+os.environ["MMSIM_LIB"] = ABL
 code = r'''
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
