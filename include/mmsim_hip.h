@@ -211,6 +211,27 @@ int mmsim_dwconv_bwd_data(const void* dz, const float* w_tap_major, const void* 
                           void* stream);
 int mmsim_dwconv_bwd_weight(const void* dz, const void* a, float* g_tap_major, int B, int Hi, int Wi, int C, int K, int S,
                             float* scratch, unsigned long long scratch_floats, void* stream);
+/* ---- LDS-tiled depthwise kernels (csrc/mbconv.hip): the timm MBConv depthwise stage under cv_classifier.py:49 with the
+ * passes either side of it folded in.  All activations NHWC bf16, w_tap_major [K*K][C] fp32 (mmsim_dw_weight_to_tap_major),
+ * scratch >= the per-block partial slabs (checked), sums pre-zeroed by the caller as for every BN-sum producer.
+ * mmsim_dwtile_fwd: z [B,Ho,Wo,C] = dwconv_KxK_stride_S(a), a = silu(xf_scale * in + xf_shift) formed while the input tile
+ *   (with halo) is staged in LDS (xf_scale / xf_shift NULL: `in` is already activated), + sums [2][C] += per-channel sum and
+ *   sum of squares of the rounded outputs (the following BatchNorm's batch statistics).
+ * mmsim_dwtile_bwd (stride 1): the whole backward of  z1 -> bn1 -> silu -> dwconv -> bn2 -> silu -> x gate  in one kernel.
+ *   dy = dLoss/d(gated activation), dsq [B,C] = dLoss/d(squeeze) from the SE backward, sums2 [2][C] = the depthwise
+ *   BatchNorm's backward sums (mmsim_bn_bwd_sums_from_pool).  Produces out = dLoss/d(z1 after bn1) x silu' (the input of
+ *   bn1's backward) with its sums1 [2][C] (+=), the tap-major depthwise weight gradient g_tap_major (+=), and
+ *   dgamma2 / dbeta2 (+=).  scale1 == NULL: DS block, z1 is the block input itself (no bn1 / silu on the data path), `resid`
+ *   (optional) is added to out, sums1 unused. */
+int mmsim_dwtile_fwd(const void* in, const float* xf_scale, const float* xf_shift, const float* w_tap_major, void* z,
+                     float* sums, int B, int Hi, int Wi, int C, int K, int S, float* scratch,
+                     unsigned long long scratch_floats, void* stream);
+int mmsim_dwtile_bwd(const void* dy, const void* z2, const float* scale2, const float* shift2, const float* mean2,
+                     const float* rstd2, const float* sums2, const float* gate, const float* dsq, const void* z1,
+                     const float* scale1, const float* shift1, const float* mean1, const float* rstd1,
+                     const void* resid, const float* w_tap_major, void* out, float* sums1, float* g_tap_major,
+                     float* dgamma2, float* dbeta2, int B, int H, int W, int C, int K, float* scratch,
+                     unsigned long long scratch_floats, void* stream);
 /* Stem: 3x3 stride-2 pad-1 conv on the NCHW fp32 image -> NHWC bf16, with the output's BN sums; and its wgrad. */
 int mmsim_stem_fwd(const float* x, const float* w, void* z, float* sums, int B, int Hi, int Wi, int Co, float* scratch,
                    unsigned long long scratch_floats, void* stream);

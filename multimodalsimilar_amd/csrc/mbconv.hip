@@ -1,0 +1,588 @@
+// LDS-tiled depthwise-convolution kernels of the MBConv block for gfx950 (NHWC bf16 activations, fp32 arithmetic).
+//
+// The round-1 depthwise kernels (conv.hip) read every input row straight from global memory once per kernel row: a 5x5
+// output strip issues 40 16-byte loads for 4 outputs and the vector-memory path, not HBM, set their rate (1.6-2.8 TB/s).
+// Here a workgroup stages an input tile WITH ITS HALO in LDS once (each global byte is requested ~1.3-1.6 times instead
+// of K times) and every tap is an LDS read.  Staging through LDS also makes it free to TRANSFORM the operand on the way in,
+// which removes whole passes over the widest tensors of the tower:
+//   dwt_fwd   in = z1 (pre-BatchNorm expand output): a1 = silu(scale z1 + shift) is formed while the tile is staged, so the
+//             activated tensor a1 is never written to / re-read from HBM (was: bn_apply pass + its output);
+//             out = z2 (+ per-channel sum / sum of squares of the rounded outputs: the next BatchNorm's statistics).
+//   dwt_bwd   (stride 1) ONE kernel for the whole depthwise backward: the tile staged in LDS is dz2, the gradient w.r.t. the
+//             depthwise output, computed on the way in from (dy, z2) = the BatchNorm + SiLU + squeeze-excite-gate backward
+//             (was a separate 3-tensor pass, bn_bwd_apply); from it both the data gradient (x silu'(bn(z1)) -> dpre1, with the
+//             expand BatchNorm's backward sums) and the weight gradient (x a1, recomputed from z1) are formed in one sweep:
+//             for centre pixel q and tap k, t = dz2[q + PAD - k]:  da1[q] += t w[k],  dW[k] += a1[q] t.
+//             (was: bn_bwd_apply + dwconv_bwd_weight + dwconv_bwd_data = 8 passes over [pixels, mid] tensors; now 4.)
+// Thread = (channel unit u, pixel lane pl): a unit is CPT = 8 (16-byte accesses) or 4 (8-byte) consecutive channels, a
+// workgroup owns OG units x a spatial tile, consecutive lanes hold consecutive units of one pixel (contiguous bytes).
+// Per-channel reductions (BN statistics, BN-backward sums, weight gradients) stay in registers over all the tiles a block
+// walks and leave as ONE partial-slab row per block (summed by reduce_partials: no atomics, bitwise reproducible).
+#include "common.h"
+
+struct DwTile {
+  int B, Hi, Wi, Ho, Wo, C;
+  int TH, TW, IH, IW;                 // output tile; staged input tile (with halo)
+  int total_tiles, tiles_per_block;   // B * tiles per image; consecutive tiles walked by one block
+  int OG, NP, nstrips;                // channel units per block, pixel lanes (256 / OG), TW / 4
+  FastDiv d_tiles_img, d_tx, d_iw, d_strips;
+};
+
+template <int CPT> struct UnitT;
+template <> struct UnitT<8> { typedef uint4 T; };
+template <> struct UnitT<4> { typedef uint2 T; };
+
+template <int CPT> __device__ __forceinline__ void unpackN(const typename UnitT<CPT>::T& v, float (&f)[CPT]);
+template <> __device__ __forceinline__ void unpackN<8>(const uint4& v, float (&f)[8]) {
+  const bf8 b = __builtin_bit_cast(bf8, v);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = bf2f(b[e]);
+}
+template <> __device__ __forceinline__ void unpackN<4>(const uint2& v, float (&f)[4]) {
+  const bf4 b = __builtin_bit_cast(bf4, v);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) f[e] = bf2f(b[e]);
+}
+template <int CPT> __device__ __forceinline__ typename UnitT<CPT>::T packN(const float (&f)[CPT]);
+template <> __device__ __forceinline__ uint4 packN<8>(const float (&f)[8]) {
+  bf8 b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) b[e] = f2bf(f[e]);
+  return __builtin_bit_cast(uint4, b);
+}
+template <> __device__ __forceinline__ uint2 packN<4>(const float (&f)[4]) {
+  bf4 b;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b[e] = f2bf(f[e]);
+  return __builtin_bit_cast(uint2, b);
+}
+// bounds-masked load: the address is always valid (callers clamp), the value is AND-masked (a select of a load makes hipcc
+// branch around it and wait vmcnt(0) per element, conv.hip)
+template <int CPT> __device__ __forceinline__ typename UnitT<CPT>::T ldN_masked(const bf16* p, bool ok);
+template <> __device__ __forceinline__ uint4 ldN_masked<8>(const bf16* p, bool ok) {
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  const unsigned int m = ok ? 0xffffffffu : 0u;
+  return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+}
+template <> __device__ __forceinline__ uint2 ldN_masked<4>(const bf16* p, bool ok) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  const unsigned int m = ok ? 0xffffffffu : 0u;
+  return make_uint2(v.x & m, v.y & m);
+}
+template <int CPT> __device__ __forceinline__ void ldNf(const float* p, float (&f)[CPT]) {
+#pragma unroll
+  for (int e = 0; e < CPT; e += 4) {
+    const float4 a = *reinterpret_cast<const float4*>(p + e);
+    f[e] = a.x; f[e + 1] = a.y; f[e + 2] = a.z; f[e + 3] = a.w;
+  }
+}
+__device__ __forceinline__ int clampi2(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// Sum acc[NV] over the pixel lanes of a block (threads pl*OG + u, same u) through `red` (>= 256*CH floats), CH values per
+// round; the pl == 0 thread of each unit ends up with the totals.
+template <int NV, int CH>
+__device__ __forceinline__ void lanes_reduce(float (&acc)[NV], float* red, int u, int pl, int OG, int NP) {
+  static_assert(NV % CH == 0, "chunking");
+#pragma unroll
+  for (int c = 0; c < NV; c += CH) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CH; ++i) red[threadIdx.x * CH + i] = acc[c + i];
+    __syncthreads();
+    if (pl == 0) {
+      for (int r = 1; r < NP; ++r)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) acc[c + i] += red[(r * OG + u) * CH + i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ forward
+template <int K, int S, bool XF>
+__global__ __launch_bounds__(256, 3) void dwt_fwd_kernel(const bf16* in, const float* scale, const float* shift, const float* wT,
+                                                         bf16* out, float* parts, DwTile g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PAD = K / 2, NIN = 3 * S + K;
+  const int tid = threadIdx.x;
+  const int u = tid % g.OG, pl = tid / g.OG;
+  const bool lane_ok = pl < g.NP;
+  const int unit = blockIdx.y * g.OG + u;
+  const bool cok = lane_ok && unit * 8 < g.C;
+  const int c0 = cok ? unit * 8 : 0;
+  const int npix = g.IH * g.IW;
+  uint4* tile = reinterpret_cast<uint4*>(smem);
+  float* wl = reinterpret_cast<float*>(smem + (size_t)npix * g.OG * 16);       // [tap][OG][8] weights of this channel group
+  for (int i = tid; i < K * K * g.OG * 8; i += 256) {
+    const int tap = i / (g.OG * 8), r = i - tap * (g.OG * 8);
+    const int c = blockIdx.y * g.OG * 8 + r;
+    wl[i] = c < g.C ? wT[(size_t)tap * g.C + c] : 0.f;
+  }
+  float st[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st[i] = 0.f;
+  const int t0 = blockIdx.x * g.tiles_per_block, t1 = min(g.total_tiles, t0 + g.tiles_per_block);
+  for (int t = t0; t < t1; ++t) {
+    int b, ti, ty, tx;
+    fdivmod((unsigned int)t, g.d_tiles_img, b, ti);
+    fdivmod((unsigned int)ti, g.d_tx, ty, tx);
+    const int oy0 = ty * g.TH, ox0 = tx * g.TW;
+    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+    __syncthreads();                      // the previous tile's taps have been read (first trip: the weights are staged)
+    if (lane_ok) {
+      float sc[8], sh[8];                 // per-phase loads: the channel vectors do not occupy registers across the tap loop
+      if (XF) { ldNf<8>(scale + c0, sc); ldNf<8>(shift + c0, sh); }
+      const bf16* inb = in + (size_t)b * g.Hi * g.Wi * g.C + c0;
+      for (int i0 = pl; i0 < npix; i0 += 4 * g.NP) {       // four pixels per trip: all loads requested before the first use
+        uint4 v[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = min(i0 + q * g.NP, npix - 1);
+          int iy, ix;
+          fdivmod((unsigned int)i, g.d_iw, iy, ix);
+          const int hy = iy0 + iy, wx = ix0 + ix;
+          ok[q] = cok && hy >= 0 && hy < g.Hi && wx >= 0 && wx < g.Wi;
+          v[q] = ldN_masked<8>(inb + ((size_t)clampi2(hy, 0, g.Hi - 1) * g.Wi + clampi2(wx, 0, g.Wi - 1)) * g.C, ok[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = i0 + q * g.NP;
+          if (i < npix) {
+            if (XF) {       // a1 = silu(bn(z1)), rounded to bf16 as the stored tensor was; padding is zero AFTER the activation
+              float f[8];
+              unpackN<8>(v[q], f);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] = ok[q] ? silu_f(f[e] * sc[e] + sh[e]) : 0.f;
+              v[q] = packN<8>(f);
+            }
+            tile[(size_t)i * g.OG + u] = v[q];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (lane_ok) {
+      const int nitems = g.TH * g.nstrips;
+      for (int it = pl; it < nitems; it += g.NP) {
+        int oy, sx;
+        fdivmod((unsigned int)it, g.d_strips, oy, sx);
+        float acc[4][8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+#pragma unroll 1
+        for (int kh = 0; kh < K; ++kh) {
+          const uint4* row = tile + ((size_t)(oy * S + kh) * g.IW + sx * 4 * S) * g.OG + u;
+          uint4 raw[NIN];
+#pragma unroll
+          for (int x = 0; x < NIN; ++x) raw[x] = row[(size_t)x * g.OG];
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            float w[8];
+            ldNf<8>(wl + ((kh * K + kw) * g.OG + u) * 8, w);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float xin[8];
+              unpackN<8>(raw[j * S + kw], xin);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[j][e] += xin[e] * w[e];
+            }
+          }
+        }
+        const int gy = oy0 + oy;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gx = ox0 + sx * 4 + j;
+          if (cok && gy < g.Ho && gx < g.Wo) {
+            const uint4 o = packN<8>(acc[j]);
+            *reinterpret_cast<uint4*>(out + (((size_t)b * g.Ho + gy) * g.Wo + gx) * g.C + c0) = o;
+            float r[8];
+            unpackN<8>(o, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { st[e] += r[e]; st[8 + e] += r[e] * r[e]; }
+          }
+        }
+      }
+    }
+  }
+  lanes_reduce<16, 16>(st, reinterpret_cast<float*>(smem), u, pl, g.OG, g.NP);
+  if (cok && pl == 0) {
+    float* slab = parts + (size_t)blockIdx.x * 2 * g.C + c0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { slab[e] = st[e]; slab[g.C + e] = st[8 + e]; }
+  }
+}
+
+// ------------------------------------------------------------------ fused backward (stride 1)
+struct DwBwd {
+  const bf16* dy; const bf16* z2; const bf16* z1; const bf16* resid;
+  const float* sc2; const float* sh2; const float* mu2; const float* rs2; const float* sums2;     // depthwise BatchNorm
+  const float* gate; const float* dsq;                                                              // [B, C] fp32
+  const float* sc1; const float* sh1; const float* mu1; const float* rs1;                          // expand BatchNorm (IR blocks)
+  const float* wT; bf16* out; float* parts_bn; float* parts_w; float* dgamma2; float* dbeta2;
+  float invP, inv_hw;
+  int RG;            // row groups of the weight-gradient phase: 256 / (OG * K)
+};
+
+// PLAIN = the depthwise conv's input was the block input itself (DS block of stage 0): a1 = x read as is, no BN + SiLU
+// backward on the data gradient, optional residual gradient added.
+// Per tile three phases, each with its own thread mapping and only the registers it needs:
+//   stage   thread (u, pixel lane): dz2 of the halo tile -> LDS (the depthwise BatchNorm + SiLU + gate backward on the way in)
+//   data    thread (u, strip of 4 centre pixels): da1 = sum_k dz2[q + PAD - k] w[k]; a1 = silu(bn(z1)) -> LDS (centre tile);
+//           dpre1 = da1 silu'(bn(z1)) -> HBM, with the expand BatchNorm's backward sums
+//   weight  thread (u, kernel row kh, row group): dW[kh][kw] += a1[q] dz2[q + PAD - k] over its rows (K x 8 accumulators)
+template <int K, bool PLAIN>
+__global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int SW = 4, NQ = 4;                    // centre pixels per strip; staged pixels per trip
+  constexpr int NIN = SW + K - 1, PAD = K / 2;
+  const int tid = threadIdx.x;
+  const int u = tid % g.OG, pl = tid / g.OG;
+  const bool lane_ok = pl < g.NP;
+  const int unit = blockIdx.y * g.OG + u;
+  const bool cok = lane_ok && unit * 8 < g.C;
+  const int c0 = cok ? unit * 8 : 0;
+  const int npix = g.IH * g.IW, ncen = g.TH * g.TW;
+  uint4* tile = reinterpret_cast<uint4*>(smem);                                            // dz2, halo tile [IH*IW][OG]
+  uint4* cen = tile + (size_t)npix * g.OG;                                                  // a1, centre tile [TH*TW][OG]
+  float* wl = reinterpret_cast<float*>(smem + (size_t)(npix + ncen) * g.OG * 16);          // [tap][OG][8]
+  for (int i = tid; i < K * K * g.OG * 8; i += 256) {
+    const int tap = i / (g.OG * 8), r = i - tap * (g.OG * 8);
+    const int c = blockIdx.y * g.OG * 8 + r;
+    wl[i] = c < g.C ? p.wT[(size_t)tap * g.C + c] : 0.f;
+  }
+  if (blockIdx.x == 0 && cok && pl == 0) {            // dgamma += sum da zhat, dbeta += sum da (the BN-backward sums themselves)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { p.dgamma2[c0 + e] += p.sums2[g.C + c0 + e]; p.dbeta2[c0 + e] += p.sums2[c0 + e]; }
+  }
+  // weight-phase mapping: thread -> (unit wu, kernel row wkh, row group wrg)
+  const int wu = tid % g.OG, wrest = tid / g.OG;
+  const int wkh = wrest % K, wrg = wrest / K;
+  const bool w_ok = wrg < p.RG && (blockIdx.y * g.OG + wu) * 8 < g.C;
+  float st[16], dW[K * 8];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < K * 8; ++i) dW[i] = 0.f;
+  const int t0 = blockIdx.x * g.tiles_per_block, t1 = min(g.total_tiles, t0 + g.tiles_per_block);
+  for (int t = t0; t < t1; ++t) {
+    int b, ti, ty, tx;
+    fdivmod((unsigned int)t, g.d_tiles_img, b, ti);
+    fdivmod((unsigned int)ti, g.d_tx, ty, tx);
+    const int oy0 = ty * g.TH, ox0 = tx * g.TW;
+    const int iy0 = oy0 - PAD, ix0 = ox0 - PAD;
+    __syncthreads();
+    // ---- stage: dz2 = scale (da - S1/P - zhat S2/P),  da = (dy gate + dsq/HW) silu'(scale z2 + shift)
+    if (lane_ok) {
+      // folded per-channel constants: dz2 = (dy gs + qs) silu'(sc2 z + sh2) - A - z Bc   with  gs = gate sc2, qs = dsq/HW sc2,
+      // Bc = sc2 rstd S2/P, A = sc2 S1/P - mean Bc
+      float sc2[8], sh2[8], gs[8], qs[8], A[8], Bc[8];
+      {
+        float mu2[8], rs2[8], m1[8], m2[8];
+        ldNf<8>(p.sc2 + c0, sc2); ldNf<8>(p.sh2 + c0, sh2); ldNf<8>(p.mu2 + c0, mu2); ldNf<8>(p.rs2 + c0, rs2);
+        ldNf<8>(p.sums2 + c0, m1); ldNf<8>(p.sums2 + g.C + c0, m2);
+        ldNf<8>(p.gate + (size_t)b * g.C + c0, gs); ldNf<8>(p.dsq + (size_t)b * g.C + c0, qs);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          gs[e] *= sc2[e]; qs[e] *= p.inv_hw * sc2[e];
+          Bc[e] = sc2[e] * rs2[e] * m2[e] * p.invP;
+          A[e] = sc2[e] * m1[e] * p.invP - mu2[e] * Bc[e];
+        }
+      }
+      const size_t img = (size_t)b * g.Ho * g.Wo * g.C + c0;
+      auto request = [&](int i0, uint4 (&vd)[NQ], uint4 (&vz)[NQ], bool (&ok)[NQ]) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int i = min(i0 + q * g.NP, npix - 1);
+          int iy, ix;
+          fdivmod((unsigned int)i, g.d_iw, iy, ix);
+          const int hy = iy0 + iy, wx = ix0 + ix;
+          ok[q] = cok && hy >= 0 && hy < g.Ho && wx >= 0 && wx < g.Wo;
+          const size_t off = img + ((size_t)clampi2(hy, 0, g.Ho - 1) * g.Wo + clampi2(wx, 0, g.Wo - 1)) * g.C;
+          vd[q] = ldN_masked<8>(p.dy + off, ok[q]);
+          vz[q] = ldN_masked<8>(p.z2 + off, ok[q]);
+        }
+      };
+      uint4 vd[NQ], vz[NQ];
+      bool ok[NQ];
+      for (int i0 = pl; i0 < npix; i0 += NQ * g.NP) {
+        request(i0, vd, vz, ok);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int i = i0 + q * g.NP;
+          if (i < npix) {
+            float d[8], z[8], o[8];
+            unpackN<8>(vd[q], d); unpackN<8>(vz[q], z);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float da = (d[e] * gs[e] + qs[e]) * silu_grad_f(z[e] * sc2[e] + sh2[e]);
+              o[e] = ok[q] ? da - A[e] - z[e] * Bc[e] : 0.f;
+            }
+            tile[(size_t)i * g.OG + u] = packN<8>(o);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- data gradient
+    if (lane_ok) {
+      float sc1[8], sh1[8], mu1[8], rs1[8];
+      if (!PLAIN) { ldNf<8>(p.sc1 + c0, sc1); ldNf<8>(p.sh1 + c0, sh1); ldNf<8>(p.mu1 + c0, mu1); ldNf<8>(p.rs1 + c0, rs1); }
+      const int nitems = g.TH * g.nstrips;
+      for (int it = pl; it < nitems; it += g.NP) {
+        int oy, sx;
+        fdivmod((unsigned int)it, g.d_strips, oy, sx);
+        const int gy = oy0 + oy, gx0 = ox0 + sx * SW;
+        const bool rowok = cok && gy < g.Hi;
+        const size_t off0 = (((size_t)b * g.Hi + min(gy, g.Hi - 1)) * g.Wi) * g.C + c0;
+        uint4 zr[SW], rr[SW];
+        bool pok[SW];
+#pragma unroll
+        for (int j = 0; j < SW; ++j) {
+          pok[j] = rowok && gx0 + j < g.Wi;
+          zr[j] = ldN_masked<8>(p.z1 + off0 + (size_t)min(gx0 + j, g.Wi - 1) * g.C, pok[j]);
+          if (PLAIN && p.resid) rr[j] = ldN_masked<8>(p.resid + off0 + (size_t)min(gx0 + j, g.Wi - 1) * g.C, pok[j]);
+        }
+        float da[SW][8];
+#pragma unroll
+        for (int j = 0; j < SW; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) da[j][e] = 0.f;
+#pragma unroll 1
+        for (int kh = 0; kh < K; ++kh) {
+          const uint4* row = tile + ((size_t)(oy + K - 1 - kh) * g.IW + sx * SW) * g.OG + u;
+          uint4 raw[NIN];
+#pragma unroll
+          for (int x = 0; x < NIN; ++x) raw[x] = row[(size_t)x * g.OG];
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            float w[8];
+            ldNf<8>(wl + ((kh * K + kw) * g.OG + u) * 8, w);
+#pragma unroll
+            for (int j = 0; j < SW; ++j) {
+              float tv[8];
+              unpackN<8>(raw[j + K - 1 - kw], tv);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) da[j][e] += tv[e] * w[e];
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < SW; ++j) {
+          float z[8], a1[8], o[8];
+          unpackN<8>(zr[j], z);
+          if (PLAIN) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a1[e] = z[e]; o[e] = da[j][e]; }          // masked load: zero outside the image
+            if (p.resid) {
+              float r[8];
+              unpackN<8>(rr[j], r);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] += r[e];
+            }
+            if (pok[j]) *reinterpret_cast<uint4*>(p.out + off0 + (size_t)(gx0 + j) * g.C) = packN<8>(o);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float uu = z[e] * sc1[e] + sh1[e], sg = sigmoid_f(uu);
+              a1[e] = pok[j] ? uu * sg : 0.f;
+              o[e] = da[j][e] * sg * (1.0f + uu * (1.0f - sg));
+            }
+            const uint4 pk = packN<8>(o);
+            if (pok[j]) {
+              *reinterpret_cast<uint4*>(p.out + off0 + (size_t)(gx0 + j) * g.C) = pk;
+              unpackN<8>(pk, o);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { st[e] += o[e]; st[8 + e] += o[e] * (z[e] - mu1[e]) * rs1[e]; }
+            }
+          }
+          cen[(size_t)(oy * g.TW + sx * SW + j) * g.OG + u] = packN<8>(a1);       // the rounded a1 the forward convolved
+        }
+      }
+    }
+    __syncthreads();
+    // ---- weight gradient
+    if (w_ok) {
+      for (int oy = wrg; oy < g.TH; oy += p.RG) {
+        const uint4* arow = cen + (size_t)(oy * g.TW) * g.OG + wu;
+        const uint4* drow = tile + (size_t)((oy + K - 1 - wkh) * g.IW) * g.OG + wu;
+        for (int sx = 0; sx < g.nstrips; ++sx) {
+          uint4 ra[SW], rd[NIN];
+#pragma unroll
+          for (int j = 0; j < SW; ++j) ra[j] = arow[(size_t)(sx * SW + j) * g.OG];
+#pragma unroll
+          for (int x = 0; x < NIN; ++x) rd[x] = drow[(size_t)(sx * SW + x) * g.OG];
+#pragma unroll
+          for (int j = 0; j < SW; ++j) {
+            float a[8];
+            unpackN<8>(ra[j], a);
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+              float tv[8];
+              unpackN<8>(rd[j + K - 1 - kw], tv);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) dW[kw * 8 + e] += a[e] * tv[e];
+            }
+          }
+        }
+      }
+    }
+  }
+  float* red = reinterpret_cast<float*>(smem);
+  if (!PLAIN) {
+    lanes_reduce<16, 16>(st, red, u, pl, g.OG, g.NP);
+    if (cok && pl == 0) {
+      float* slab = p.parts_bn + (size_t)blockIdx.x * 2 * g.C + c0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { slab[e] = st[e]; slab[g.C + e] = st[8 + e]; }
+    }
+  }
+  // weight-gradient partials: sum over the row groups (threads (wrg * K + wkh) * OG + wu), one slab row per block
+#pragma unroll          // unrolled: dW must stay in registers (a runtime-indexed array goes to scratch)
+  for (int kw = 0; kw < K; ++kw) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[tid * 8 + e] = w_ok ? dW[kw * 8 + e] : 0.f;
+    __syncthreads();
+    if (w_ok && wrg == 0) {
+      float a[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = dW[kw * 8 + e];
+      for (int r = 1; r < p.RG; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += red[(((r * K + wkh) * g.OG) + wu) * 8 + e];
+      float* slab = p.parts_w + (size_t)blockIdx.x * K * K * g.C + (size_t)(wkh * K + kw) * g.C + (blockIdx.y * g.OG + wu) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) slab[e] = a[e];
+    }
+  }
+}
+
+// ================================================================= host side
+void mmsim_launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s);   // conv.hip
+
+
+// Channel units per block: a divisor of the unit count near `target` octets (8 = 128 B per pixel) when there is one, so that
+// no block carries idle lanes.  Planes so small that a tile is the whole plane (7x7) have fewer strips than a block of
+// 8-octet groups has pixel lanes (14 strips for 42 lanes: two thirds of the block idles through the tap loop): they take
+// wider groups so that strips ~ pixel lanes.
+static int pick_og(int units, int target) {
+  if (units <= target + target / 2) return units;           // the whole channel dimension in one group
+  int best = 0;
+  for (int d = target / 2; d <= 2 * target; ++d)
+    if (units % d == 0 && (best == 0 || abs(d - target) < abs(best - target))) best = d;
+  return best ? best : target;
+}
+
+// Output tile: TW a multiple of 4 (strips of four outputs per thread), chosen to minimise the staged-to-produced pixel
+// ratio (halo + clipped overhang) under the LDS budget.
+static void pick_tile(int Ho, int Wo, int K, int S, int og, bool bwd, int* th, int* tw) {
+  double best = 1e30;
+  *th = 4; *tw = 4;
+  const long budget = bwd ? 72 * 1024 : 40 * 1024;      // backward: two workgroups per CU (registers), forward three to four
+  for (int TW = 4; TW <= ((Wo + 3) & ~3) && TW <= 32; TW += 4) {
+    for (int TH = 2; TH <= Ho && TH <= 32; ++TH) {
+      const int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+      const long lds = ((long)IH * IW + (bwd ? (long)TH * TW : 0)) * og * 16 + (long)K * K * og * 32;
+      if (lds > budget) break;
+      const int tx = (Wo + TW - 1) / TW, ty = (Ho + TH - 1) / TH;
+      const double cost = ((double)tx * ty * IH * IW / (S * S) + 0.5 * tx * ty * TH * TW) / ((double)Ho * Wo);
+      if (cost < best - 1e-9) { best = cost; *th = TH; *tw = TW; }
+    }
+  }
+}
+
+static int make_geom(DwTile* g, int B, int Hi, int Wi, int C, int K, int S, bool bwd, bool xf, size_t* lds, dim3* grid) {
+  const int cpt = 8;
+  MMSIM_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && C > 0 && (C % 8) == 0, "dwtile: bad geometry (C must be a multiple of 8)");
+  MMSIM_REQUIRE((K == 3 || K == 5) && (S == 1 || S == 2), "dwtile: kernel 3/5 and stride 1/2 only");
+  g->B = B; g->Hi = Hi; g->Wi = Wi; g->C = C;
+  g->Ho = (Hi + 2 * (K / 2) - K) / S + 1; g->Wo = (Wi + 2 * (K / 2) - K) / S + 1;
+  const int units = C / cpt;
+  const int strips_plane = g->Ho * ((g->Wo + 3) / 4);
+  g->OG = pick_og(units, strips_plane <= 16 ? 16 : 8);
+  while (g->OG * K > 256) g->OG /= 2;
+  g->NP = 256 / g->OG;
+  pick_tile(g->Ho, g->Wo, K, S, g->OG, bwd, &g->TH, &g->TW);
+  g->IH = (g->TH - 1) * S + K; g->IW = (g->TW - 1) * S + K;
+  g->nstrips = g->TW / 4;
+  const int tx = (g->Wo + g->TW - 1) / g->TW, ty = (g->Ho + g->TH - 1) / g->TH;
+  g->total_tiles = B * tx * ty;
+  const int gy = (units + g->OG - 1) / g->OG;
+  int want = 2048 / gy; if (want < 1) want = 1;
+  g->tiles_per_block = (g->total_tiles + want - 1) / want;
+  g->d_tiles_img = make_fastdiv(tx * ty); g->d_tx = make_fastdiv(tx); g->d_iw = make_fastdiv(g->IW); g->d_strips = make_fastdiv(g->nstrips);
+  size_t need = ((size_t)g->IH * g->IW + (bwd ? (size_t)g->TH * g->TW : 0)) * g->OG * 16 + (size_t)K * K * g->OG * 32;
+  const size_t red = 256 * 16 * sizeof(float);            // the end-of-block reductions reuse the tile region
+  *lds = need > red ? need : red;
+  *grid = dim3((g->total_tiles + g->tiles_per_block - 1) / g->tiles_per_block, gy);
+  return MMSIM_OK;
+}
+
+// more than 64 KiB of dynamic LDS needs the per-(function, device) opt-in
+static void optin_bwd_lds() {
+  static unsigned long long done = 0;
+  const int dev = mmsim_current_device();
+  if ((done >> dev) & 1) return;
+  const int cap = 96 * 1024;
+  (void)hipFuncSetAttribute((const void*)dwt_bwd_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  (void)hipFuncSetAttribute((const void*)dwt_bwd_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  (void)hipFuncSetAttribute((const void*)dwt_bwd_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  (void)hipFuncSetAttribute((const void*)dwt_bwd_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  done |= 1ull << dev;
+}
+
+extern "C" int mmsim_dwtile_fwd(const void* in, const float* xf_scale, const float* xf_shift, const float* w_tap_major, void* z,
+                                float* sums, int B, int Hi, int Wi, int C, int K, int S, float* scratch,
+                                unsigned long long scratch_floats, void* stream) {
+  MMSIM_REQUIRE(in && w_tap_major && z && sums && scratch, "dwtile_fwd: null operand");
+  MMSIM_REQUIRE((xf_scale == nullptr) == (xf_shift == nullptr), "dwtile_fwd: scale and shift come together");
+  DwTile g; size_t lds; dim3 grid;
+  int rc = make_geom(&g, B, Hi, Wi, C, K, S, false, xf_scale != nullptr, &lds, &grid); if (rc) return rc;
+  MMSIM_REQUIRE(scratch_floats >= (unsigned long long)grid.x * 2 * C, "dwtile_fwd: scratch too small");
+  hipStream_t s = (hipStream_t)stream;
+#define DWT_F(KK, SS, XX) hipLaunchKernelGGL((dwt_fwd_kernel<KK, SS, XX>), grid, dim3(256), lds, s, (const bf16*)in, xf_scale, xf_shift, w_tap_major, (bf16*)z, scratch, g)
+#define DWT_FX(XX)                                                                        \
+  if (K == 3 && S == 1) DWT_F(3, 1, XX); else if (K == 3 && S == 2) DWT_F(3, 2, XX);     \
+  else if (K == 5 && S == 1) DWT_F(5, 1, XX); else DWT_F(5, 2, XX);
+  if (xf_scale) { DWT_FX(true) } else { DWT_FX(false) }
+#undef DWT_FX
+#undef DWT_F
+  mmsim_launch_reduce(scratch, grid.x, 2 * C, sums, 1, s);      /* sums += (pre-zeroed by the caller) */
+  return mmsim_check_launch("dwtile_fwd");
+}
+
+extern "C" int mmsim_dwtile_bwd(const void* dy, const void* z2, const float* scale2, const float* shift2, const float* mean2,
+                                const float* rstd2, const float* sums2, const float* gate, const float* dsq, const void* z1,
+                                const float* scale1, const float* shift1, const float* mean1, const float* rstd1,
+                                const void* resid, const float* w_tap_major, void* out, float* sums1, float* g_tap_major,
+                                float* dgamma2, float* dbeta2, int B, int H, int W, int C, int K, float* scratch,
+                                unsigned long long scratch_floats, void* stream) {
+  MMSIM_REQUIRE(dy && z2 && scale2 && shift2 && mean2 && rstd2 && sums2 && gate && dsq && z1 && w_tap_major && out && g_tap_major &&
+                    dgamma2 && dbeta2 && scratch, "dwtile_bwd: null operand");
+  const bool plain = scale1 == nullptr;
+  MMSIM_REQUIRE(plain ? (!shift1 && !mean1 && !rstd1) : (shift1 && mean1 && rstd1 && sums1 && !resid),
+                "dwtile_bwd: the expand BatchNorm state comes as a whole (IR block, no resid) or not at all (DS block)");
+  DwTile g; size_t lds; dim3 grid;
+  int rc = make_geom(&g, B, H, W, C, K, 1, true, true, &lds, &grid); if (rc) return rc;
+  const size_t n_bn = plain ? 0 : (size_t)grid.x * 2 * C, n_w = (size_t)grid.x * K * K * C;
+  MMSIM_REQUIRE(scratch_floats >= (unsigned long long)(n_bn + n_w), "dwtile_bwd: scratch too small");
+  DwBwd p;
+  p.dy = (const bf16*)dy; p.z2 = (const bf16*)z2; p.z1 = (const bf16*)z1; p.resid = (const bf16*)resid;
+  p.sc2 = scale2; p.sh2 = shift2; p.mu2 = mean2; p.rs2 = rstd2; p.sums2 = sums2; p.gate = gate; p.dsq = dsq;
+  p.sc1 = scale1; p.sh1 = shift1; p.mu1 = mean1; p.rs1 = rstd1; p.wT = w_tap_major; p.out = (bf16*)out;
+  p.parts_bn = scratch; p.parts_w = scratch + n_bn; p.dgamma2 = dgamma2; p.dbeta2 = dbeta2;
+  p.invP = 1.0f / (float)((size_t)B * H * W); p.inv_hw = 1.0f / (float)(H * W);
+  p.RG = 256 / (g.OG * K); if (p.RG < 1) p.RG = 1;
+  MMSIM_REQUIRE(g.OG * K <= 256, "dwtile_bwd: channel group too wide for the weight-gradient mapping");
+  hipStream_t s = (hipStream_t)stream;
+  optin_bwd_lds();
+#define DWT_B(KK, PP) hipLaunchKernelGGL((dwt_bwd_kernel<KK, PP>), grid, dim3(256), lds, s, p, g)
+  if (K == 3) { if (plain) DWT_B(3, true); else DWT_B(3, false); }
+  else { if (plain) DWT_B(5, true); else DWT_B(5, false); }
+#undef DWT_B
+  if (!plain) mmsim_launch_reduce(p.parts_bn, grid.x, 2 * C, sums1, 1, s);
+  mmsim_launch_reduce(p.parts_w, grid.x, K * K * C, g_tap_major, 1, s);
+  return mmsim_check_launch("dwtile_bwd");
+}

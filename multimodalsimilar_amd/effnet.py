@@ -69,6 +69,9 @@ def count_macs(model_name, res=224):
 # MMSIM_KEEP_A2=0: do not keep the activated depthwise output; the projection conv then applies BN + SiLU + gate while it
 # stages its operand (saves one [pixels, mid] bf16 tensor per block, costs ~2 ms/step at cfg4: those products become VALU-bound)
 _KEEP_A2 = os.environ.get("MMSIM_KEEP_A2", "1") != "0"
+# MMSIM_DWTILE=0: the round-1 depthwise kernels (rows straight from global memory; separate bn_apply / bn_bwd_apply passes)
+# instead of the LDS-tiled ones of csrc/mbconv.hip (A/B switch)
+_DWTILE = os.environ.get("MMSIM_DWTILE", "1") != "0"
 
 class _Holder(nn.Module):
     pass
@@ -304,9 +307,12 @@ class EfficientNet(nn.Module):
             lib.gemm_bf16_bnstats(0, P_in, b.mid, b.cin, cur.data_ptr(), b.cin, w1.data_ptr(), b.cin, bs.z1.data_ptr(), b.mid,
                                   None, None, None, 1, sm.data_ptr(), *self._scr(), s)     # conv + the BN statistics of z1
             self._bn_finalize(st, n + "." + e_bn, sm, P_in)
-            bs.a1 = E(P_in, b.mid)
-            lib.bn_apply(bs.z1.data_ptr(), self._bnp(st, n + "." + e_bn, 2).data_ptr(),
-                         self._bnp(st, n + "." + e_bn, 3).data_ptr(), None, bs.a1.data_ptr(), P_in, b.mid, 1, s)
+            if _DWTILE and b.stride == 1:
+                bs.a1 = None          # a1 = silu(bn(z1)) is formed inside the depthwise kernels, never materialised
+            else:
+                bs.a1 = E(P_in, b.mid)
+                lib.bn_apply(bs.z1.data_ptr(), self._bnp(st, n + "." + e_bn, 2).data_ptr(),
+                             self._bnp(st, n + "." + e_bn, 3).data_ptr(), None, bs.a1.data_ptr(), P_in, b.mid, 1, s)
         else:
             bs.a1 = cur
         Ho, Wo = (H + b.stride - 1) // b.stride, (W + b.stride - 1) // b.stride
@@ -315,7 +321,14 @@ class EfficientNet(nn.Module):
         lib.dw_weight_to_tap_major(V(n + ".conv_dw.weight").data_ptr(), bs.wT.data_ptr(), b.mid, b.k, s)
         bs.z2 = E(P_out, b.mid)
         sm = self._sums(st, n + "." + d_bn, "f")
-        lib.dwconv_fwd(bs.a1.data_ptr(), bs.wT.data_ptr(), bs.z2.data_ptr(), sm.data_ptr(), B, H, W, b.mid, b.k, b.stride, *self._scr(), s)
+        if not _DWTILE:
+            lib.dwconv_fwd(bs.a1.data_ptr(), bs.wT.data_ptr(), bs.z2.data_ptr(), sm.data_ptr(), B, H, W, b.mid, b.k, b.stride, *self._scr(), s)
+        elif bs.a1 is None:
+            lib.dwtile_fwd(bs.z1.data_ptr(), self._bnp(st, n + "." + e_bn, 2).data_ptr(), self._bnp(st, n + "." + e_bn, 3).data_ptr(),
+                           bs.wT.data_ptr(), bs.z2.data_ptr(), sm.data_ptr(), B, H, W, b.mid, b.k, b.stride, *self._scr(), s)
+        else:
+            lib.dwtile_fwd(bs.a1.data_ptr(), None, None, bs.wT.data_ptr(), bs.z2.data_ptr(), sm.data_ptr(), B, H, W, b.mid, b.k,
+                           b.stride, *self._scr(), s)
         self._bn_finalize(st, n + "." + d_bn, sm, P_out)
         sc2, sh2 = self._bnp(st, n + "." + d_bn, 2), self._bnp(st, n + "." + d_bn, 3)
         bs.s = E(B, b.mid, dt=torch.float32)
@@ -454,23 +467,45 @@ class EfficientNet(nn.Module):
                        dr.data_ptr(), ds.data_ptr(), dweT.data_ptr(), G(n + ".se.conv_reduce.weight").data_ptr(),
                        G(n + ".se.conv_reduce.bias").data_ptr(), G(n + ".se.conv_expand.weight").data_ptr(),
                        G(n + ".se.conv_expand.bias").data_ptr(), B, b.mid, b.rd, s)
-        dz2 = E(P_out, b.mid)
         lib.bn_bwd_sums_from_pool(out5.data_ptr(), bs.gate.data_ptr(), ds.data_ptr(), self._sums(st, n + "." + d_bn, "b").data_ptr(),
                                   B, Ho * Wo, b.mid, s)
-        self._bn_bwd(st, n + "." + d_bn, da2g, bs.z2, P_out, b.mid, dz2, act=True, gate=bs.gate, dsq=ds, hw=Ho * Wo,
-                     sums_ready=True)
-        del da2g
         if not hasattr(st, "gT_all"):
             self._zero_gT(st)
         gT = st.gT_all[st.gT_off[n]:st.gT_off[n] + b.k * b.k * b.mid]
-        lib.dwconv_bwd_weight(dz2.data_ptr(), bs.a1.data_ptr(), gT.data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride, *self._scr(), s)
+        fused = _DWTILE and b.stride == 1
+        if fused:
+            # ONE kernel: depthwise-BN + SiLU + gate backward (on the way into LDS), depthwise data and weight gradients,
+            # expand-BN + SiLU backward on the way out (mmsim_dwtile_bwd)
+            bnp = lambda nm, i: self._bnp(st, nm, i).data_ptr()
+            dn = n + "." + d_bn
+            common = (da2g.data_ptr(), bs.z2.data_ptr(), bnp(dn, 2), bnp(dn, 3), bnp(dn, 0), bnp(dn, 1),
+                      self._sums(st, dn, "b").data_ptr(), bs.gate.data_ptr(), ds.data_ptr())
+            if b.type == "ir":
+                en = n + "." + e_bn
+                dpre1 = E(P_in, b.mid)
+                lib.dwtile_bwd(*common, bs.z1.data_ptr(), bnp(en, 2), bnp(en, 3), bnp(en, 0), bnp(en, 1), None, bs.wT.data_ptr(),
+                               dpre1.data_ptr(), self._sums(st, en, "b").data_ptr(), gT.data_ptr(), G(dn + ".weight").data_ptr(),
+                               G(dn + ".bias").data_ptr(), B, Hn, Wn, b.mid, b.k, *self._scr(), s)
+            else:
+                dx_in = E(P_in, b.cin)
+                lib.dwtile_bwd(*common, bs.x_in.data_ptr(), None, None, None, None, dx.data_ptr() if b.skip else None,
+                               bs.wT.data_ptr(), dx_in.data_ptr(), None, gT.data_ptr(), G(dn + ".weight").data_ptr(),
+                               G(dn + ".bias").data_ptr(), B, Hn, Wn, b.mid, b.k, *self._scr(), s)
+            del da2g
+        else:
+            dz2 = E(P_out, b.mid)
+            self._bn_bwd(st, n + "." + d_bn, da2g, bs.z2, P_out, b.mid, dz2, act=True, gate=bs.gate, dsq=ds, hw=Ho * Wo,
+                         sums_ready=True)
+            del da2g
+            lib.dwconv_bwd_weight(dz2.data_ptr(), bs.a1.data_ptr(), gT.data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride, *self._scr(), s)
         lib.dw_grad_from_tap_major(gT.data_ptr(), G(n + ".conv_dw.weight").data_ptr(), b.mid, b.k, s)
         if b.type == "ir":
             en = n + "." + e_bn
-            dpre1 = E(P_in, b.mid)
-            lib.dwconv_bwd_data(dz2.data_ptr(), bs.wT.data_ptr(), bs.z1.data_ptr(), self._bnp(st, en, 0).data_ptr(),
-                                self._bnp(st, en, 1).data_ptr(), self._bnp(st, en, 2).data_ptr(), self._bnp(st, en, 3).data_ptr(),
-                                None, dpre1.data_ptr(), self._sums(st, en, "b").data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride,
+            if not fused:
+                dpre1 = E(P_in, b.mid)
+                lib.dwconv_bwd_data(dz2.data_ptr(), bs.wT.data_ptr(), bs.z1.data_ptr(), self._bnp(st, en, 0).data_ptr(),
+                                    self._bnp(st, en, 1).data_ptr(), self._bnp(st, en, 2).data_ptr(), self._bnp(st, en, 3).data_ptr(),
+                                    None, dpre1.data_ptr(), self._sums(st, en, "b").data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride,
                                     *self._scr(), s)
             dz1 = E(P_in, b.mid)
             self._bn_bwd(st, en, dpre1, bs.z1, P_in, b.mid, dz1, act=False, sums_ready=True)
@@ -480,7 +515,7 @@ class EfficientNet(nn.Module):
             dx_in = E(P_in, b.cin)
             ops.gemm(dz1, SV(n + ".conv_pw.weight", (b.mid, b.cin)), dx_in, b_kmajor=False,
                      epilogue=ops.EPI_ADD if b.skip else ops.EPI_NONE, aux_in=dx if b.skip else None)
-        else:
+        elif not fused:
             dx_in = E(P_in, b.cin)
             lib.dwconv_bwd_data(dz2.data_ptr(), bs.wT.data_ptr(), None, None, None, None, None,
                                 dx.data_ptr() if b.skip else None, dx_in.data_ptr(), None, B, Hn, Wn, b.mid, b.k, b.stride,

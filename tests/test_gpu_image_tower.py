@@ -93,6 +93,85 @@ def test_depthwise_conv_fwd_bwd(K, S, H, C):
     assert relerr(g - 1, wr.grad) < 1e-2
 
 
+@pytest.mark.parametrize("K,S,H,C,xf", [(3, 1, 12, 48, True), (5, 1, 10, 40, True), (3, 2, 16, 144, False), (5, 2, 14, 192, False),
+                                          (3, 1, 7, 272, True), (5, 1, 14, 960, True), (3, 1, 30, 24, False), (5, 1, 28, 336, True),
+                                          (3, 2, 18, 1632, True)])
+def test_tiled_depthwise_forward(K, S, H, C, xf):
+    """LDS-tiled depthwise forward (csrc/mbconv.hip) with the producer's BN + SiLU applied while the tile is staged, against
+    fp32 torch: conv of the ROUNDED activation, zero padding after the activation, statistics of the rounded outputs."""
+    lib, s = _lib()
+    B, W = 3, H + 3
+    z1 = nhwc(rnd(B, C, H, W, seed=1))
+    scale, shift = 1 + 0.1 * rnd(C, seed=8), 0.1 * rnd(C, seed=9)
+    w = rnd(C, 1, K, K, seed=2, scale=0.3)
+    a = F.silu(z1.float() * scale + shift).bfloat16() if xf else z1
+    ref = F.conv2d(nchw(a, B, H, W), w, None, stride=S, padding=K // 2, groups=C)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    wT = torch.empty(K * K, C, device=DEV)
+    lib.dw_weight_to_tap_major(w.data_ptr(), wT.data_ptr(), C, K, s)
+    z = torch.full((B * Ho * Wo, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    sums = torch.zeros(2 * C, device=DEV)
+    lib.dwtile_fwd(z1.data_ptr(), scale.data_ptr() if xf else None, shift.data_ptr() if xf else None, wT.data_ptr(), z.data_ptr(),
+                   sums.data_ptr(), B, H, W, C, K, S, *scr(), s)
+    assert relerr(nchw(z, B, Ho, Wo), ref) < 1e-2
+    zf = z.float()
+    assert relerr(sums[:C], zf.sum(0)) < 1e-3 and relerr(sums[C:], (zf * zf).sum(0)) < 1e-3
+
+
+@pytest.mark.parametrize("K,H,C,plain,resid", [(3, 12, 48, False, False), (5, 10, 40, False, False), (3, 7, 272, False, False),
+                                               (5, 14, 960, False, False), (3, 30, 24, True, True), (3, 20, 48, True, False),
+                                               (5, 28, 336, False, False), (5, 7, 1632, False, False), (3, 56, 192, False, False)])
+def test_tiled_depthwise_backward_equals_the_unfused_kernels(K, H, C, plain, resid):
+    """mmsim_dwtile_bwd (one kernel: depthwise-BN + SiLU + gate backward, data + weight gradients, expand-BN + SiLU backward
+    on the way out) against the sequence it replaces -- bn_bwd, dwconv_bwd_weight, dwconv_bwd_data -- whose members are checked
+    against fp32 torch autograd above."""
+    lib, s = _lib()
+    B, W = 3, H + 1
+    P, HW = B * H * W, H * W
+    z2 = rnd(P, C, seed=1, scale=1.5).bfloat16()
+    dy = rnd(P, C, seed=2).bfloat16()
+    z1 = rnd(P, C, seed=3, scale=1.5).bfloat16()
+    w = rnd(C, 1, K, K, seed=4, scale=0.3)
+    gate, dsq = torch.sigmoid(rnd(B, C, seed=5)), rnd(B, C, seed=6)
+    mk = lambda sd: (rnd(C, seed=sd, scale=0.1), 1 + 0.1 * rnd(C, seed=sd + 1).abs(), 1 + 0.1 * rnd(C, seed=sd + 2), 0.1 * rnd(C, seed=sd + 3))
+    mu2, rs2, sc2, sh2 = mk(10)
+    mu1, rs1, sc1, sh1 = mk(20)
+    res = rnd(P, C, seed=7).bfloat16() if resid else None
+    wT = torch.empty(K * K, C, device=DEV)
+    lib.dw_weight_to_tap_major(w.data_ptr(), wT.data_ptr(), C, K, s)
+    # ---- the unfused sequence
+    sums2 = torch.zeros(2 * C, device=DEV)
+    dz2 = torch.empty(P, C, dtype=torch.bfloat16, device=DEV)
+    dg_ref, db_ref = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    lib.bn_bwd(dy.data_ptr(), z2.data_ptr(), mu2.data_ptr(), rs2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), gate.data_ptr(),
+               dsq.data_ptr(), HW, 1, sums2.data_ptr(), 0, dz2.data_ptr(), dg_ref.data_ptr(), db_ref.data_ptr(), P, C, *scr(), s)
+    a1 = z1 if plain else F.silu(z1.float() * sc1 + sh1).bfloat16()
+    gT_ref = torch.zeros(K * K, C, device=DEV)
+    lib.dwconv_bwd_weight(dz2.data_ptr(), a1.data_ptr(), gT_ref.data_ptr(), B, H, W, C, K, 1, *scr(), s)
+    out_ref = torch.empty(P, C, dtype=torch.bfloat16, device=DEV)
+    sums1_ref = torch.zeros(2 * C, device=DEV)
+    if plain:
+        lib.dwconv_bwd_data(dz2.data_ptr(), wT.data_ptr(), None, None, None, None, None, res.data_ptr() if resid else None,
+                            out_ref.data_ptr(), None, B, H, W, C, K, 1, *scr(), s)
+    else:
+        lib.dwconv_bwd_data(dz2.data_ptr(), wT.data_ptr(), z1.data_ptr(), mu1.data_ptr(), rs1.data_ptr(), sc1.data_ptr(), sh1.data_ptr(),
+                            None, out_ref.data_ptr(), sums1_ref.data_ptr(), B, H, W, C, K, 1, *scr(), s)
+    # ---- the fused kernel
+    out = torch.full((P, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    sums1, gT = torch.zeros(2 * C, device=DEV), torch.zeros(K * K, C, device=DEV)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    n = lambda t: None if t is None else t.data_ptr()
+    lib.dwtile_bwd(dy.data_ptr(), z2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), mu2.data_ptr(), rs2.data_ptr(), sums2.data_ptr(),
+                   gate.data_ptr(), dsq.data_ptr(), z1.data_ptr(), *(4 * [None] if plain else [sc1.data_ptr(), sh1.data_ptr(), mu1.data_ptr(), rs1.data_ptr()]),
+                   n(res), wT.data_ptr(), out.data_ptr(), None if plain else sums1.data_ptr(), gT.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                   B, H, W, C, K, *scr(), s)
+    assert relerr(out, out_ref) < 1e-2
+    assert relerr(gT, gT_ref) < 5e-3
+    assert relerr(dg, dg_ref) < 1e-5 and relerr(db, db_ref) < 1e-5
+    if not plain:
+        assert relerr(sums1, sums1_ref) < 5e-3
+
+
 @pytest.mark.parametrize("C,P", [(24, 1000), (336, 777), (2688, 98)])
 def test_batchnorm_stats_apply_backward(C, P):
     lib, s = _lib()
