@@ -33,7 +33,10 @@ const char* mmsim_last_error(void);
  * as called from transformer_emb.py:20-24), F.linear in arcface.py:47, timm 1x1 convs under
  * cv_classifier.py:49, nn.Linear cv_classifier.py:53 -- and autograd's dgrad / wgrad of each.
  * epilogue: 0 none | 1 GELU(erf): aux_out <- pre-activation, C <- gelu | 2 C <- acc * gelu'(aux_in)
- *           | 3 C <- acc + aux_in | 4 tanh | 5 row-fix (f32 C, see mmsim_arcface_rowfix; bias then holds [2][M] row vectors).   split_k > 1 adds atomically into an f32 C (gradient buffers);
+ *           | 3 C <- acc + aux_in | 4 tanh | 5 row-fix (f32 C, see mmsim_arcface_rowfix; bias then holds [2][M] row vectors)
+ *           | 6 GELU(erf): aux_out <- gelu'(pre-activation), C <- gelu | 7 C <- acc * aux_in  (6 / 7: the pair the text tower
+ *             trains with: BertIntermediate, modeling_bert.py:334-337, and its backward as one multiply).
+ * split_k > 1 adds atomically into an f32 C (gradient buffers);
  * accumulate != 0 makes C += result for split_k == 1 as well (f32 C only).
  * K-major operands must be zero in [K, round_up(K,8)) of each row when K % 8 != 0. */
 int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B, int ldb,

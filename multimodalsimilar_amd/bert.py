@@ -30,6 +30,9 @@ from ._lib import MmsimError
 _FUSE_ATTN_BIAS = os.environ.get("MMSIM_FUSE_BIAS_GRADS", "1") != "0"
 # MMSIM_WGRAD_PAIR=0: the attention-output and q|k|v weight gradients of a layer as two launches instead of one grouped launch
 _WGRAD_PAIR = os.environ.get("MMSIM_WGRAD_PAIR", "1") != "0"
+# MMSIM_GELU_PAIR=0: the intermediate activation keeps its pre-activation and the dgrad epilogue recomputes gelu' from it
+# (epilogues 1 / 2) instead of saving gelu' in forward and multiplying in backward (epilogues 6 / 7); A/B switch
+_GELU_PAIR = os.environ.get("MMSIM_GELU_PAIR", "1") != "0"
 
 class BertConfig:
     """The subset of HF BertConfig the tower needs (defaults: hfl/chinese-roberta-wwm-ext)."""
@@ -288,7 +291,7 @@ class BertModel(nn.Module):
             ops.add_ln_fwd(ws.t, x, V(p + "attention.output.LayerNorm.weight"), V(p + "attention.output.LayerNorm.bias"),
                            ws.y1[k], ws.h1[k], st[0], st[1], cfg.layer_norm_eps, ph, seed, 4 * li + 1)
             ops.gemm(ws.h1[k], fl.sview(p + "intermediate.dense.weight"), ws.u[k], bias=V(p + "intermediate.dense.bias"),
-                     epilogue=ops.EPI_GELU, aux_out=ws.upre[k])
+                     epilogue=ops.EPI_GELU_DGELU if _GELU_PAIR else ops.EPI_GELU, aux_out=ws.upre[k])       # upre holds gelu'(pre-activation): the dgrad epilogue is one multiply
             ops.gemm(ws.u[k], fl.sview(p + "output.dense.weight"), ws.t, bias=V(p + "output.dense.bias"))
             ops.add_ln_fwd(ws.t, ws.h1[k], V(p + "output.LayerNorm.weight"), V(p + "output.LayerNorm.bias"),
                            ws.y2[k], ws.h[k + 1] if keep else ws.h[0], st[2], st[3], cfg.layer_norm_eps, ph, seed,
@@ -332,7 +335,7 @@ class BertModel(nn.Module):
                        G(p + "output.LayerNorm.weight"), G(p + "output.LayerNorm.bias"), G(p + "output.dense.bias"),
                        m.ph, m.seed, 4 * li + 2)
             ops.gemm(dT, ws.u[li], G(p + "output.dense.weight"), trans_a=True, b_kmajor=False, split_k=skI, accumulate=True)
-            ops.gemm(dT, SV(p + "output.dense.weight"), ws.du, b_kmajor=False, epilogue=ops.EPI_MUL_GELU_GRAD,
+            ops.gemm(dT, SV(p + "output.dense.weight"), ws.du, b_kmajor=False, epilogue=ops.EPI_MUL if _GELU_PAIR else ops.EPI_MUL_GELU_GRAD,
                      aux_in=ws.upre[li])
             ops.colsum(ws.du, G(p + "intermediate.dense.bias"))
             ops.gemm(ws.du, ws.h1[li], G(p + "intermediate.dense.weight"), trans_a=True, b_kmajor=False, split_k=skI,

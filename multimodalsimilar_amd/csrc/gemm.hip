@@ -254,11 +254,11 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   MMSIM_REQUIRE((ldc % 4) == 0, "gemm: ldc must be a multiple of 4");
   MMSIM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
                 "gemm: operands must be 16-byte aligned");
-  MMSIM_REQUIRE(epilogue >= 0 && epilogue <= 5, "gemm: unknown epilogue");
+  MMSIM_REQUIRE(epilogue >= 0 && epilogue <= 7, "gemm: unknown epilogue");
   MMSIM_REQUIRE(epilogue != EPI_ROWFIX || (c_is_f32 && split_k == 1 && bias && aux_in),
                 "gemm: the row-fix epilogue needs an f32 output, no split-K, the [2][M] row vectors in bias and aux_in");
-  MMSIM_REQUIRE(!(epilogue == EPI_GELU) || aux_out, "gemm: GELU epilogue needs aux_out (pre-activation)");
-  MMSIM_REQUIRE(!(epilogue == EPI_MUL_GELU_GRAD || epilogue == EPI_ADD) || aux_in, "gemm: epilogue needs aux_in");
+  MMSIM_REQUIRE(!(epilogue == EPI_GELU || epilogue == EPI_GELU_DGELU) || aux_out, "gemm: GELU epilogues need aux_out (pre-activation / gelu')");
+  MMSIM_REQUIRE(!(epilogue == EPI_MUL_GELU_GRAD || epilogue == EPI_ADD || epilogue == EPI_MUL) || aux_in, "gemm: epilogue needs aux_in");
   MMSIM_REQUIRE(epilogue == EPI_NONE || (ld_aux % 4) == 0 || epilogue == EPI_TANH, "gemm: ld_aux must be a multiple of 4");
   MMSIM_REQUIRE(split_k >= 1, "gemm: split_k >= 1");
   MMSIM_REQUIRE(split_k == 1 || (c_is_f32 && epilogue == EPI_NONE), "gemm: split-K needs f32 output and no epilogue");

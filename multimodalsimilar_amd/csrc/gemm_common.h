@@ -20,7 +20,17 @@ struct GemmParams {
 
 // EPI_ROWFIX: C[m][n] (+)= r[m] * (acc - aux_in[m][n] * r[M + m]) with the two fp32 row vectors r passed in `bias` ([2][M]):
 // the backward of a row L2-normalisation folded into the product that feeds it (ArcFace weight gradient, head.py).
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_MUL_GELU_GRAD = 2, EPI_ADD = 3, EPI_TANH = 4, EPI_ROWFIX = 5 };
+// EPI_GELU_DGELU / EPI_MUL: the GELU pair the text tower uses.  Forward: out = gelu(pre) and aux_out = gelu'(pre) (the erf is
+// shared, one more exp) -- so the dgrad epilogue is ONE multiply per element by a prefetched operand instead of erf + exp on
+// the GEMM's critical path (EPI_MUL_GELU_GRAD recomputes gelu' from the stored pre-activation: ~7 us of VALU per 256x256 tile).
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_MUL_GELU_GRAD = 2, EPI_ADD = 3, EPI_TANH = 4, EPI_ROWFIX = 5, EPI_GELU_DGELU = 6, EPI_MUL = 7 };
+
+// gelu(x) and gelu'(x) from one erf
+__device__ __forceinline__ void gelu_both_f(float x, float& g, float& dg) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  g = x * cdf;
+  dg = cdf + x * (0.39894228040143268f * __expf(-0.5f * x * x));
+}
 
 // Epilogue for full tiles, staged through LDS so that every global access is row-contiguous: the wave's 64x64
 // fp32 tile is written to its private LDS region (the operand ring is free by then) and read back one row segment
@@ -45,6 +55,19 @@ __device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][
     return;
   }
   const int c4 = (lane & 15) * 4, n = col0 + c4;
+  // Epilogues that READ a [M, N] operand (GELU' / residual / multiplier): on full tiles all 16 row segments of the lane are
+  // requested up front -- ahead of the staging round trip through LDS -- instead of four at a time inside the row loop (each
+  // group of four paid a full memory round trip with the matrix pipe idle: ~30 us per 256x256 tile on the FFN dgrad product).
+  constexpr bool PRE = !CHECK && CMODE != 3 && (EPI == EPI_MUL_GELU_GRAD || EPI == EPI_ADD || EPI == EPI_MUL);
+  bf4 auxv[16];
+  if (PRE) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const size_t m = (size_t)(row0 + it * 4 + (lane >> 4));
+      if (EPI == EPI_ADD) auxv[it] = *reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n);
+      else auxv[it] = __builtin_nontemporal_load(reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n));      // read once
+    }
+  }
   const bool add_bias = (p.bias != nullptr) && first_split && EPI != EPI_ROWFIX;
   float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
   if (add_bias) {
@@ -60,7 +83,9 @@ __device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][
       for (int e = 0; e < 4 && n + e < p.N; ++e) {
         float v = tile[r * EP_PITCH + c4 + e] * p.alpha + bb[e];
         if (EPI == EPI_GELU) { const bf16 pre = f2bf(v); p.aux_out[m * p.ld_aux + n + e] = pre; v = gelu_f(bf2f(pre)); }
+        else if (EPI == EPI_GELU_DGELU) { float g, dg; gelu_both_f(bf2f(f2bf(v)), g, dg); p.aux_out[m * p.ld_aux + n + e] = f2bf(dg); v = g; }
         else if (EPI == EPI_MUL_GELU_GRAD) v *= gelu_grad_f(bf2f(p.aux_in[m * p.ld_aux + n + e]));
+        else if (EPI == EPI_MUL) v *= bf2f(p.aux_in[m * p.ld_aux + n + e]);
         else if (EPI == EPI_ADD) v += bf2f(p.aux_in[m * p.ld_aux + n + e]);
         else if (EPI == EPI_ROWFIX) v = p.bias[m] * (v - bf2f(p.aux_in[m * p.ld_aux + n + e]) * p.bias[(size_t)p.M + m]);
         else if (EPI == EPI_TANH) v = tanhf(v);
@@ -71,24 +96,32 @@ __device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][
     }
     return;
   }
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
+  auto row_body = [&](int it) __attribute__((always_inline)) {
     const int r = it * 4 + (lane >> 4);
-    if (CHECK && row0 + r >= p.M) continue;
+    if (CHECK && row0 + r >= p.M) return;
     const size_t m = (size_t)(row0 + r);
     const f4 a = *reinterpret_cast<const f4*>(tile + r * EP_PITCH + c4);
     float v[4] = {a[0] * p.alpha + bias.x, a[1] * p.alpha + bias.y, a[2] * p.alpha + bias.z, a[3] * p.alpha + bias.w};
-    if (EPI == EPI_GELU) {
+    if (EPI == EPI_GELU_DGELU) {
+      bf4 dg;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { float g, d; gelu_both_f(bf2f(f2bf(v[e])), g, d); v[e] = g; dg[e] = f2bf(d); }      // of the rounded pre-activation
+      __builtin_nontemporal_store(dg, reinterpret_cast<bf4*>(p.aux_out + m * p.ld_aux + n));      // only read again in backward
+    } else if (EPI == EPI_MUL) {
+      const bf4 x = PRE ? auxv[it] : __builtin_nontemporal_load(reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= bf2f(x[e]);
+    } else if (EPI == EPI_GELU) {
       bf4 pre = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
       __builtin_nontemporal_store(pre, reinterpret_cast<bf4*>(p.aux_out + m * p.ld_aux + n));      // only read again in backward
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = gelu_f(bf2f(pre[e]));
     } else if (EPI == EPI_MUL_GELU_GRAD) {
-      const bf4 x = __builtin_nontemporal_load(reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n));      // read once
+      const bf4 x = PRE ? auxv[it] : __builtin_nontemporal_load(reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n));      // read once
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(bf2f(x[e]));
     } else if (EPI == EPI_ADD) {
-      const bf4 x = *reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n);
+      const bf4 x = PRE ? auxv[it] : *reinterpret_cast<const bf4*>(p.aux_in + m * p.ld_aux + n);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] += bf2f(x[e]);
     } else if (EPI == EPI_TANH) {
@@ -112,6 +145,13 @@ __device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][
         *reinterpret_cast<float4*>(c) = make_float4(v[0] + old.x, v[1] + old.y, v[2] + old.z, v[3] + old.w);
       }
     }
+  };
+  if (PRE) {          // the prefetched operands are register-array elements: their index must be a compile-time constant
+#pragma unroll
+    for (int it = 0; it < 16; ++it) row_body(it);
+  } else {
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) row_body(it);
   }
 }
 
@@ -156,6 +196,8 @@ __device__ __forceinline__ void fast_epilogue_epi(const GemmParams& p, f4 (&acc)
     case EPI_MUL_GELU_GRAD: fast_epilogue<EPI_MUL_GELU_GRAD, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile); break;
     case EPI_ADD: fast_epilogue<EPI_ADD, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile); break;
     case EPI_TANH: fast_epilogue<EPI_TANH, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile); break;
+    case EPI_GELU_DGELU: fast_epilogue<EPI_GELU_DGELU, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile); break;
+    case EPI_MUL: fast_epilogue<EPI_MUL, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile); break;
     default: fast_epilogue<EPI_NONE, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile); break;
   }
 }
@@ -192,6 +234,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f4 (&acc)[4][
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_f(bf2f(f2bf(v[e])));   // gelu of the stored (rounded) pre-activation
+      } else if (p.epi == EPI_GELU_DGELU) {
+        bf16* ao = p.aux_out + (size_t)m * p.ld_aux + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.N) { float g, dg; gelu_both_f(bf2f(f2bf(v[e])), g, dg); ao[e] = f2bf(dg); v[e] = g; }
+      } else if (p.epi == EPI_MUL) {
+        const bf16* ai = p.aux_in + (size_t)m * p.ld_aux + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.N) v[e] *= bf2f(ai[e]);
       } else if (p.epi == EPI_MUL_GELU_GRAD) {
         const bf16* ai = p.aux_in + (size_t)m * p.ld_aux + n;
 #pragma unroll

@@ -319,10 +319,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     if (sacc == 12345.678f) reinterpret_cast<float*>(p.C)[0] = sacc;
     return;
   }
-#pragma unroll
-  for (int half = 0; half < MT / 4; ++half) {
+  // the two 64-row halves of a wave's sub-tile, written out explicitly: the accumulator array must only ever be indexed
+  // with compile-time constants (an un-unrolled loop over `half` sends all 128 accumulators to scratch)
+  auto epi_half = [&](f4 (&a4)[4][4], int half) __attribute__((always_inline)) {
     __syncthreads();
-    f4 (&a4)[4][4] = *reinterpret_cast<f4 (*)[4][4]>(&acc[half * 4][0]);
     const int row0 = m0 + wm * WROWS + half * 64, col0 = n0 + wn * 64;
     if (!p.c_f32) fast_epilogue_epi<0>(p, a4, row0, col0, lane, fs, stg);
     else if (GRP && second) {              // the second product's output (grouped launches are split-K atomics only)
@@ -334,7 +334,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     else if (p.accum) fast_epilogue<EPI_NONE, 2>(p, a4, row0, col0, lane, fs, stg);
     else if (p.epi == EPI_TANH) fast_epilogue<EPI_TANH, 1>(p, a4, row0, col0, lane, fs, stg);
     else fast_epilogue<EPI_NONE, 1>(p, a4, row0, col0, lane, fs, stg);
-  }
+  };
+  epi_half(*reinterpret_cast<f4 (*)[4][4]>(&acc[0][0]), 0);
+  if constexpr (MT == 8) epi_half(*reinterpret_cast<f4 (*)[4][4]>(&acc[4][0]), 1);
 }
 
 static bool pipe_eligible(const GemmParams& p, int splits, int bn) {

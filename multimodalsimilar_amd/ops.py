@@ -14,7 +14,7 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 I64 = torch.int64
 
-EPI_NONE, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_ADD, EPI_TANH, EPI_ROWFIX = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_ADD, EPI_TANH, EPI_ROWFIX, EPI_GELU_DGELU, EPI_MUL = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 def _stream():

@@ -79,6 +79,14 @@ def test_gemm_epilogues_and_splitk():
     r = rnd(M, N, seed=6).bfloat16()
     ops.gemm(a, b, c, epilogue=ops.EPI_ADD, aux_in=r)
     assert relerr(c, pre - bias + r.float()) < 1e-2
+    # the pair the text tower trains with: GELU that saves gelu'(pre) (of the ROUNDED pre-activation), and the plain multiply
+    dg = torch.empty_like(c)
+    ops.gemm(a, b, c, bias=bias, epilogue=ops.EPI_GELU_DGELU, aux_out=dg)
+    xr = pre.bfloat16().float().requires_grad_(True)
+    F.gelu(xr).sum().backward()
+    assert relerr(c, F.gelu(pre)) < 1e-2 and relerr(dg, xr.grad) < 1e-2
+    ops.gemm(a, b, c, epilogue=ops.EPI_MUL, aux_in=dg)
+    assert relerr(c, (pre - bias) * dg.float()) < 1e-2
     # split-K atomic accumulation on top of existing contents, and plain accumulate
     at = a.t().contiguous()        # [K, M] -> product over K as the slow index
     bt = b.t().contiguous()
