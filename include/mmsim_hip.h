@@ -235,6 +235,16 @@ int mmsim_dwtile_bwd(const void* dy, const void* z2, const float* scale2, const 
                      const void* resid, const float* w_tap_major, void* out, float* sums1, float* g_tap_major,
                      float* dgamma2, float* dbeta2, int B, int H, int W, int C, int K, float* scratch,
                      unsigned long long scratch_floats, void* stream);
+/* mmsim_pw_expand_bwd: the backward of an MBConv block's expand stage  x -> conv_pw (W1) -> z1 -> bn1 (train mode)  in one
+ * streaming pass (timm conv_pw + bn1 under cv_classifier.py:49): dpre = dLoss/d(bn1 output) [P, mid] (what mmsim_dwtile_bwd
+ * leaves), sums1 [2][mid] = bn1's backward sums.  dx [P, cin] = dz1 W1 (+ resid), dw1 [mid, cin] += dz1^T x,
+ * dgamma1 / dbeta1 += the sums, with dz1 = scale1 (dpre - S1/P - zhat S2/P) formed on the way into LDS.  Replaces
+ * mmsim_bn_bwd + two mmsim_gemm_bf16 calls.  Shapes: mmsim_pw_expand_bwd_eligible (W1 and dW1 must fit LDS / registers). */
+int mmsim_pw_expand_bwd_eligible(int P, int mid, int cin);
+int mmsim_pw_expand_bwd(const void* dpre, const void* z1, const void* x, const void* resid, const void* w1_bf16,
+                        const float* scale1, const float* mean1, const float* rstd1, const float* sums1, void* dx,
+                        float* dw1, float* dgamma1, float* dbeta1, int P, int mid, int cin, float* scratch,
+                        unsigned long long scratch_floats, void* stream);
 /* Stem: 3x3 stride-2 pad-1 conv on the NCHW fp32 image -> NHWC bf16, with the output's BN sums; and its wgrad. */
 int mmsim_stem_fwd(const float* x, const float* w, void* z, float* sums, int B, int Hi, int Wi, int Co, float* scratch,
                    unsigned long long scratch_floats, void* stream);

@@ -586,3 +586,189 @@ extern "C" int mmsim_dwtile_bwd(const void* dy, const void* z2, const float* sca
   mmsim_launch_reduce(p.parts_w, grid.x, K * K * C, g_tap_major, 1, s);
   return mmsim_check_launch("dwtile_bwd");
 }
+
+// ================================================================= fused backward of the expand stage (early MBConv blocks)
+//   x [P, cin] -> conv_pw (W1 [mid, cin]) -> z1 [P, mid] -> bn1 (train) -> silu -> ...
+// Given dpre = dLoss/d(bn1 output) (what mmsim_dwtile_bwd leaves) and bn1's backward sums, ONE streaming pass forms
+//   dz1 = scale (dpre - S1/P - zhat S2/P)        (in registers, on the way into LDS; never written to HBM)
+//   dx  = dz1 W1 (+ resid)                       (MFMA, A = the staged strip)
+//   dW1 += dz1^T x                               (MFMA, both operands through transposing LDS reads; accumulators live in
+//                                                 registers across all the strips a block walks, one partial slab per block)
+// replacing bn_bwd_apply (3 passes over [P, mid]) and the two products that each re-read dz1 (2 passes): 2 passes instead of 5
+// over the widest tensors of the tower.  Only where W1 and dW1 are small enough to live in LDS / registers -- mid <= 352,
+// cin <= 64: stages 1-2, which is where those tensors exceed the 256 MB Infinity Cache and every pass is an HBM pass.
+struct PwBwd {
+  const bf16* dpre; const bf16* z1; const bf16* x; const bf16* resid; const bf16* w1;
+  const float* sc1; const float* mu1; const float* rs1; const float* sums1;
+  bf16* dx; float* parts; float* dgamma; float* dbeta;
+  int P, mid, cin, nstrips, KS;      // KS = ceil(mid / 32)
+  float invP;
+};
+
+__device__ __forceinline__ f4 mfma16(bf8 first, bf8 second, f4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(first, second, acc, 0, 0, 0);      // acc[e] = C[second row lane&15][first row 4(lane>>4)+e]
+}
+
+template <int BM, int CIN_T, int MAXW>
+__global__ __launch_bounds__(256) void pw_expand_bwd_kernel(PwBwd p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NCH = 6;                                  // 16-byte chunks per thread and tensor of one strip (host checks)
+  constexpr int XP = CIN_T * 32 + 16;                     // X / W1 image pitch (bytes)
+  constexpr int MTD = BM / 16;                            // pixel tiles of the dgrad product
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = p.mid >> 3;                               // channel octets
+  const int ZP = p.KS * 64 + 16;                          // Z image pitch (bytes): KS*32 channels + pad
+  char* zimg = smem;                                      // [BM][KS*32] bf16: dz1 of the strip, k-major
+  char* ximg = zimg + BM * ZP;                            // [BM][CIN_T*16] bf16: x of the strip
+  char* wimg = ximg + BM * XP;                            // [KS*32][CIN_T*16] bf16: W1 (rows = mid)
+  float* cst = reinterpret_cast<float*>(wimg + p.KS * 32 * XP);      // [3][mid]: scale, A, Bc
+  // ---- one-time staging: zero the images (pads must be zero), W1, the folded BatchNorm-backward constants
+  for (int i = tid; i < (BM * ZP + BM * XP + p.KS * 32 * XP) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  for (int i = tid; i < p.mid * (p.cin >> 3); i += 256) {
+    const int r = i / (p.cin >> 3), c = i - r * (p.cin >> 3);
+    *reinterpret_cast<uint4*>(wimg + r * XP + c * 16) = *reinterpret_cast<const uint4*>(p.w1 + (size_t)r * p.cin + c * 8);
+  }
+  for (int c = tid; c < p.mid; c += 256) {
+    const float sc = p.sc1[c], bc = sc * p.rs1[c] * p.sums1[p.mid + c] * p.invP;
+    cst[c] = sc; cst[p.mid + c] = sc * p.sums1[c] * p.invP - p.mu1[c] * bc; cst[2 * p.mid + c] = bc;
+    if (blockIdx.x == 0) { p.dgamma[c] += p.sums1[p.mid + c]; p.dbeta[c] += p.sums1[c]; }
+  }
+  const int nwt = ((p.mid + 15) >> 4) * CIN_T;            // weight-gradient tiles (16 x 16), dealt round-robin to the waves
+  f4 dW[MAXW];
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) dW[i] = f4{0.f, 0.f, 0.f, 0.f};
+  const int nchunks = BM * G;
+  uint4 vd[NCH], vz[NCH];
+  auto request = [&](int strip) {
+    const size_t base = (size_t)strip * BM * p.mid;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int q = min(tid + 256 * i, nchunks - 1);
+      vd[i] = *reinterpret_cast<const uint4*>(p.dpre + base + (size_t)q * 8);
+      vz[i] = *reinterpret_cast<const uint4*>(p.z1 + base + (size_t)q * 8);
+    }
+  };
+  int strip = blockIdx.x;
+  if (strip < p.nstrips) request(strip);
+  for (; strip < p.nstrips; strip += gridDim.x) {
+    __syncthreads();                     // the previous strip's MFMAs have read the images (first trip: the staging above)
+    // ---- dz1 -> Z image, x -> X image
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int q = tid + 256 * i;
+      if (q < nchunks) {
+        const int pix = q / G, un = q - pix * G;
+        const bf8 d = __builtin_bit_cast(bf8, vd[i]), z = __builtin_bit_cast(bf8, vz[i]);
+        const float* cs = cst + un * 8;
+        bf8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(cs[e] * bf2f(d[e]) - cs[p.mid + e] - bf2f(z[e]) * cs[2 * p.mid + e]);
+        *reinterpret_cast<bf8*>(zimg + pix * ZP + un * 16) = o;
+      }
+    }
+    {
+      const int xg = p.cin >> 3;
+      for (int q = tid; q < BM * xg; q += 256) {
+        const int pix = q / xg, un = q - pix * xg;
+        *reinterpret_cast<uint4*>(ximg + pix * XP + un * 16) =
+            *reinterpret_cast<const uint4*>(p.x + ((size_t)strip * BM + pix) * p.cin + un * 8);
+      }
+    }
+    __syncthreads();
+    if (strip + (int)gridDim.x < p.nstrips) request(strip + gridDim.x);      // the next strip's loads fly under the MFMAs
+    // ---- dx = dz1 W1: (BM/16) x CIN_T tiles over the waves
+    for (int t = wave; t < MTD * CIN_T; t += 4) {
+      const int mt = t / CIN_T, nt = t - mt * CIN_T;
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < p.KS; ++ks) {
+        const bf8 zf = *reinterpret_cast<const bf8*>(zimg + (mt * 16 + (lane & 15)) * ZP + (ks * 4 + (lane >> 4)) * 16);
+        const bf8 wf = tr_frag16(wimg, XP, ks * 32, nt * 16, lane);
+        acc = mfma16(wf, zf, acc);
+      }
+      const int pix = mt * 16 + (lane & 15), ci = nt * 16 + (lane >> 4) * 4;
+      if (ci < p.cin) {                  // cin is a multiple of 8: a 4-channel group is valid as a whole
+        const size_t off = ((size_t)strip * BM + pix) * p.cin + ci;
+        if (p.resid) {
+          const bf4 r = *reinterpret_cast<const bf4*>(p.resid + off);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += bf2f(r[e]);
+        }
+        const bf4 o = {f2bf(acc[0]), f2bf(acc[1]), f2bf(acc[2]), f2bf(acc[3])};
+        *reinterpret_cast<bf4*>(p.dx + off) = o;
+      }
+    }
+    // ---- dW1 += dz1^T x: tiles (mid/16) x CIN_T, reduction over the strip's pixels
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i) {
+      const int t = wave + 4 * i;
+      if (t < nwt) {                     // wave-uniform: EXEC stays all ones for the transposing reads
+        const int mt = t / CIN_T, nt = t - mt * CIN_T;
+#pragma unroll
+        for (int ks = 0; ks < BM / 32; ++ks) {
+          const bf8 zt = tr_frag16(zimg, ZP, ks * 32, mt * 16, lane);
+          const bf8 xt = tr_frag16(ximg, XP, ks * 32, nt * 16, lane);
+          dW[i] = mfma16(xt, zt, dW[i]);
+        }
+      }
+    }
+  }
+  // ---- this block's partial weight gradient: slab row [mid][cin] fp32
+  float* slab = p.parts + (size_t)blockIdx.x * p.mid * p.cin;
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) {
+    const int t = wave + 4 * i;
+    if (t < nwt) {
+      const int mt = t / CIN_T, nt = t - mt * CIN_T;
+      const int cm = mt * 16 + (lane & 15), ci = nt * 16 + (lane >> 4) * 4;
+      if (cm < p.mid && ci < p.cin) *reinterpret_cast<f4*>(slab + (size_t)cm * p.cin + ci) = dW[i];
+    }
+  }
+}
+
+template <int BM, int CIN_T, int MAXW>
+static int launch_pw_expand_bwd(PwBwd p, float* dw1, hipStream_t s, float* scratch, unsigned long long scratch_floats) {
+  p.nstrips = p.P / BM;
+  p.KS = (p.mid + 31) / 32;
+  const int ZP = p.KS * 64 + 16, XP = CIN_T * 32 + 16;
+  const size_t lds = (size_t)BM * ZP + (size_t)BM * XP + (size_t)p.KS * 32 * XP + (size_t)3 * p.mid * 4;
+  int grid = p.nstrips < 768 ? p.nstrips : 768;
+  const size_t slab = (size_t)p.mid * p.cin;
+  while (grid > 64 && (size_t)grid * slab > scratch_floats) grid /= 2;
+  MMSIM_REQUIRE((size_t)grid * slab <= scratch_floats, "pw_expand_bwd: scratch too small");
+  MMSIM_REQUIRE(BM * (p.mid >> 3) <= 256 * 6, "pw_expand_bwd: strip too wide for the staging registers");
+  MMSIM_REQUIRE(((p.mid + 15) / 16) * CIN_T <= 4 * MAXW, "pw_expand_bwd: weight gradient does not fit the accumulators");
+  static unsigned long long done = 0;
+  const int dev = mmsim_current_device();
+  if (!((done >> dev) & 1)) {
+    (void)hipFuncSetAttribute((const void*)pw_expand_bwd_kernel<BM, CIN_T, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    done |= 1ull << dev;
+  }
+  MMSIM_REQUIRE(lds <= 96 * 1024, "pw_expand_bwd: LDS images too large");
+  p.parts = scratch;
+  hipLaunchKernelGGL((pw_expand_bwd_kernel<BM, CIN_T, MAXW>), dim3(grid), dim3(256), lds, s, p);
+  mmsim_launch_reduce(scratch, grid, (int)slab, dw1, 1, s);
+  return mmsim_check_launch("pw_expand_bwd");
+}
+
+extern "C" int mmsim_pw_expand_bwd_eligible(int P, int mid, int cin) {
+  if (P <= 0 || (P % 64) || (mid % 8) || (cin % 8)) return 0;
+  if (cin <= 32 && mid <= 192) return 1;
+  if (cin <= 64 && mid <= 336 && (P % 32) == 0) return 1;
+  return 0;
+}
+
+extern "C" int mmsim_pw_expand_bwd(const void* dpre, const void* z1, const void* x, const void* resid, const void* w1_bf16,
+                                   const float* scale1, const float* mean1, const float* rstd1, const float* sums1, void* dx,
+                                   float* dw1, float* dgamma1, float* dbeta1, int P, int mid, int cin, float* scratch,
+                                   unsigned long long scratch_floats, void* stream) {
+  MMSIM_REQUIRE(dpre && z1 && x && w1_bf16 && scale1 && mean1 && rstd1 && sums1 && dx && dw1 && dgamma1 && dbeta1 && scratch,
+                "pw_expand_bwd: null operand");
+  MMSIM_REQUIRE(mmsim_pw_expand_bwd_eligible(P, mid, cin), "pw_expand_bwd: shape not eligible (see mmsim_pw_expand_bwd_eligible)");
+  PwBwd p;
+  p.dpre = (const bf16*)dpre; p.z1 = (const bf16*)z1; p.x = (const bf16*)x; p.resid = (const bf16*)resid; p.w1 = (const bf16*)w1_bf16;
+  p.sc1 = scale1; p.mu1 = mean1; p.rs1 = rstd1; p.sums1 = sums1; p.dx = (bf16*)dx; p.dgamma = dgamma1; p.dbeta = dbeta1;
+  p.P = P; p.mid = mid; p.cin = cin; p.invP = 1.0f / (float)P;
+  if (cin <= 32 && mid <= 192) return launch_pw_expand_bwd<64, 2, 6>(p, dw1, (hipStream_t)stream, scratch, scratch_floats);
+  return launch_pw_expand_bwd<32, 4, 22>(p, dw1, (hipStream_t)stream, scratch, scratch_floats);
+}

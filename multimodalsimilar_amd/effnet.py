@@ -72,6 +72,8 @@ _KEEP_A2 = os.environ.get("MMSIM_KEEP_A2", "1") != "0"
 # MMSIM_DWTILE=0: the round-1 depthwise kernels (rows straight from global memory; separate bn_apply / bn_bwd_apply passes)
 # instead of the LDS-tiled ones of csrc/mbconv.hip (A/B switch)
 _DWTILE = os.environ.get("MMSIM_DWTILE", "1") != "0"
+# MMSIM_PW_FUSED=0: expand-stage backward as bn_bwd + two GEMMs instead of the one-pass mmsim_pw_expand_bwd (A/B switch)
+_PW_FUSED = os.environ.get("MMSIM_PW_FUSED", "1") != "0"
 
 class _Holder(nn.Module):
     pass
@@ -507,14 +509,24 @@ class EfficientNet(nn.Module):
                                     self._bnp(st, en, 1).data_ptr(), self._bnp(st, en, 2).data_ptr(), self._bnp(st, en, 3).data_ptr(),
                                     None, dpre1.data_ptr(), self._sums(st, en, "b").data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride,
                                     *self._scr(), s)
-            dz1 = E(P_in, b.mid)
-            self._bn_bwd(st, en, dpre1, bs.z1, P_in, b.mid, dz1, act=False, sums_ready=True)
-            del dpre1
-            ops.gemm(dz1, bs.x_in, G(n + ".conv_pw.weight").view(b.mid, b.cin), trans_a=True, b_kmajor=False,
-                     split_k=ops.pick_split_k(b.mid, b.cin, P_in), accumulate=True)
-            dx_in = E(P_in, b.cin)
-            ops.gemm(dz1, SV(n + ".conv_pw.weight", (b.mid, b.cin)), dx_in, b_kmajor=False,
-                     epilogue=ops.EPI_ADD if b.skip else ops.EPI_NONE, aux_in=dx if b.skip else None)
+            if _PW_FUSED and lib.pw_expand_bwd_eligible(P_in, b.mid, b.cin):
+                # one streaming pass: bn1 backward applied on the way into LDS, dx and dW1 out of the same staged strip
+                dx_in = E(P_in, b.cin)
+                lib.pw_expand_bwd(dpre1.data_ptr(), bs.z1.data_ptr(), bs.x_in.data_ptr(), dx.data_ptr() if b.skip else None,
+                                  SV(n + ".conv_pw.weight", (b.mid, b.cin)).data_ptr(), self._bnp(st, en, 2).data_ptr(),
+                                  self._bnp(st, en, 0).data_ptr(), self._bnp(st, en, 1).data_ptr(),
+                                  self._sums(st, en, "b").data_ptr(), dx_in.data_ptr(), G(n + ".conv_pw.weight").data_ptr(),
+                                  G(en + ".weight").data_ptr(), G(en + ".bias").data_ptr(), P_in, b.mid, b.cin, *self._scr(), s)
+                del dpre1
+            else:
+                dz1 = E(P_in, b.mid)
+                self._bn_bwd(st, en, dpre1, bs.z1, P_in, b.mid, dz1, act=False, sums_ready=True)
+                del dpre1
+                ops.gemm(dz1, bs.x_in, G(n + ".conv_pw.weight").view(b.mid, b.cin), trans_a=True, b_kmajor=False,
+                         split_k=ops.pick_split_k(b.mid, b.cin, P_in), accumulate=True)
+                dx_in = E(P_in, b.cin)
+                ops.gemm(dz1, SV(n + ".conv_pw.weight", (b.mid, b.cin)), dx_in, b_kmajor=False,
+                         epilogue=ops.EPI_ADD if b.skip else ops.EPI_NONE, aux_in=dx if b.skip else None)
         elif not fused:
             dx_in = E(P_in, b.cin)
             lib.dwconv_bwd_data(dz2.data_ptr(), bs.wT.data_ptr(), None, None, None, None, None,

@@ -172,6 +172,49 @@ def test_tiled_depthwise_backward_equals_the_unfused_kernels(K, H, C, plain, res
         assert relerr(sums1, sums1_ref) < 5e-3
 
 
+@pytest.mark.parametrize("P,mid,cin,skip", [(1280, 192, 32, True), (6400, 144, 24, False), (832, 336, 56, True), (64, 48, 8, False),
+                                             (2048, 192, 32, False)])
+def test_fused_expand_backward_equals_bn_backward_plus_two_products(P, mid, cin, skip):
+    """mmsim_pw_expand_bwd (BatchNorm backward on the way into LDS, dx and dW1 from the same staged strip) against the sequence
+    it replaces: mmsim_bn_bwd (sums given) + the dgrad and wgrad products."""
+    from multimodalsimilar_amd import ops
+    lib, s = _lib()
+    assert lib.pw_expand_bwd_eligible(P, mid, cin) == 1
+    dpre = rnd(P, mid, seed=1).bfloat16()
+    z1 = rnd(P, mid, seed=2, scale=1.5).bfloat16()
+    x = rnd(P, cin, seed=3).bfloat16()
+    res = rnd(P, cin, seed=4).bfloat16() if skip else None
+    w1 = rnd(mid, cin, seed=5, scale=0.2).bfloat16()
+    mean, rstd, scale = rnd(mid, seed=6, scale=0.1), 1 + 0.1 * rnd(mid, seed=7).abs(), 1 + 0.1 * rnd(mid, seed=8)
+    shift = 0.1 * rnd(mid, seed=9)
+    # the BatchNorm-backward sums of dpre (what mmsim_dwtile_bwd / mmsim_dwconv_bwd_data leave)
+    df, zh = dpre.float(), (z1.float() - mean) * rstd
+    sums = torch.cat([df.sum(0), (df * zh).sum(0)]).contiguous()
+    # ---- unfused
+    dz1 = torch.empty(P, mid, dtype=torch.bfloat16, device=DEV)
+    dg_ref, db_ref = torch.zeros(mid, device=DEV), torch.zeros(mid, device=DEV)
+    lib.bn_bwd(dpre.data_ptr(), z1.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, 1, 0,
+               sums.data_ptr(), 1, dz1.data_ptr(), dg_ref.data_ptr(), db_ref.data_ptr(), P, mid, *scr(), s)
+    gw_ref = torch.full((mid, cin), 0.5, device=DEV)
+    ops.gemm(dz1, x, gw_ref, trans_a=True, b_kmajor=False, accumulate=True)
+    dx_ref = torch.empty(P, cin, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(dz1, w1, dx_ref, b_kmajor=False, epilogue=ops.EPI_ADD if skip else ops.EPI_NONE, aux_in=res)
+    # ---- fused
+    gw = torch.full((mid, cin), 0.5, device=DEV)
+    dx = torch.full((P, cin), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dg, db = torch.zeros(mid, device=DEV), torch.zeros(mid, device=DEV)
+    lib.pw_expand_bwd(dpre.data_ptr(), z1.data_ptr(), x.data_ptr(), None if res is None else res.data_ptr(), w1.data_ptr(),
+                      scale.data_ptr(), mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(), dx.data_ptr(), gw.data_ptr(), dg.data_ptr(),
+                      db.data_ptr(), P, mid, cin, *scr(), s)
+    assert relerr(dx, dx_ref) < 1e-2
+    assert relerr(gw - 0.5, gw_ref - 0.5) < 5e-3
+    assert relerr(dg, dg_ref) < 1e-5 and relerr(db, db_ref) < 1e-5
+    # and against fp32 autograd of the same formulae (both paths round dz1 to bf16)
+    dz = scale * (df - sums[:mid] / P - zh * sums[mid:] / P)
+    assert relerr(dx, dz @ w1.float() + (res.float() if skip else 0)) < 1.5e-2
+    assert relerr(gw - 0.5, dz.t() @ x.float()) < 1e-2
+
+
 @pytest.mark.parametrize("C,P", [(24, 1000), (336, 777), (2688, 98)])
 def test_batchnorm_stats_apply_backward(C, P):
     lib, s = _lib()
