@@ -257,6 +257,10 @@ def main():
             "config": {"workload": f"{args.config}: " + {"multimodal": f"roberta-wwm-ext-{cfg.get('text')} + {cfg.get('image')} two-tower + ArcFace",
                                                         "nlp": "text tower + ArcFace", "cv": "image tower + ArcFace"}[cfg["kind"]],
                        "per_gpu_batch": cfg["batch"], "global_batch": world * cfg["batch"], "seq_len": cfg.get("seq_len"),
+                       # what the process group actually is: ranks RCCL (backend "nccl" on ROCm) connected, one per GPU
+                       "dist_backend": dist.get_backend() if world > 1 else None,
+                       "ranks_in_process_group": dist.get_world_size() if world > 1 else 1,
+                       "head": type(model.classifier).__name__,
                        "image": cfg.get("res"), "classes": cfg["classes"], "parallelism": f"dp{world}",
                        "dropout": not args.no_dropout, "attention_mask": "ragged U{8..S}" if args.ragged_masks else "all ones", "loss_path": "literal" if args.literal_loss else "fused",
                        "algorithmic_gflop_per_pair": fpp / 1e9,

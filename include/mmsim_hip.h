@@ -138,6 +138,20 @@ int mmsim_arcface_ce(const float* cosm, int ld, const long long* label, float* l
 int mmsim_arcface_dlogits_to_dcos(const float* dlogits, int ld_dl, const float* cosm, int ld, const long long* label,
                                   void* dcos, int B, int C, float s, float m, int easy_margin, void* stream);
 
+/* ---- class-sharded ArcFace head (data parallelism with the [C, D] weight split by class range over the ranks; the loss
+ * semantics kept are the reference's: softmax over ALL classes, nlp_classifier_train_daodian_v2_dist.py:139-144).
+ * cos: the local columns [class_offset, class_offset + C_local) of the cosine matrix for all B rows of the global batch; labels
+ * are global class indices.  mmsim_arcface_ce_partial leaves per row stats[b][4] = {local max logit, sum exp(logit - max),
+ * target logit or 0, 1 if the target is local} and arg[b] = global index of the local argmax; after the ranks have exchanged the
+ * stats, mmsim_arcface_dcos_from_lse writes dcos (bf16 [B, ld], pad zeroed) of the local columns from the row's global
+ * log-sum-exp: dcos = row_scale[b] * s * slope * (softmax - onehot). */
+int mmsim_arcface_ce_partial(const float* cosm, int ld, const long long* label, float* stats, long long* arg, int B,
+                             int C_local, long long class_offset, long long C_total, float s, float m, int easy_margin,
+                             int* err_flag, void* stream);
+int mmsim_arcface_dcos_from_lse(const float* cosm, int ld, const long long* label, const float* lse, const float* row_scale,
+                                void* dcos, int B, int C_local, long long class_offset, float s, float m, int easy_margin,
+                                void* stream);
+
 /* Weight-gradient path of the head without the fp32 dW_hat round trip: rowvec [2][C] <- (inv_w[c], sum_b dcos[b][c] cos[b][c]);
  * mmsim_gemm_bf16 with epilogue 5 (row-fix: C[m][n] (+)= bias[m] * (acc - aux_in[m][n] * bias[M + m]), bias = rowvec,
  * aux_in = W_hat bf16) then writes dW = (dW_hat - w_hat (w_hat . dW_hat)) / ||w|| straight into the gradient buffer: the

@@ -120,6 +120,74 @@ __global__ __launch_bounds__(256) void arcface_ce_kernel(const float* cosm, int 
   }
 }
 
+// ---- class-sharded head (data parallelism with the [C, D] weight split over the ranks by class range).
+// A rank holds the columns [c0, c0 + C) of the cosine matrix for ALL rows of the global batch.  Phase 1 leaves each row's
+// partial softmax statistics over the local columns; the ranks exchange them (a few floats per row), and phase 2 forms dcos of
+// the local columns from the row's GLOBAL log-sum-exp.  Labels are global class indices.
+//   stats[b] = { local max logit, sum exp(logit - local max), target logit (0 if the target is another rank's), 1 if target here }
+//   arg[b]   = global index of the local argmax (ties: lowest index)
+__global__ __launch_bounds__(256) void arcface_ce_partial_kernel(const float* cosm, int ld, const int64_t* label, float* stats,
+                                                                 long long* arg, int C, long long c0, long long c_total, Margin m,
+                                                                 int* err) {
+  __shared__ float sh_f[8];
+  __shared__ int sh_i[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t yg = label[b];
+  if (tid == 0 && (yg < 0 || yg >= c_total)) atomicExch(err, 1);
+  const int64_t y = yg - c0;                                   // local column of the target, if it is one of ours
+  const bool here = y >= 0 && y < C;
+  const float* row = cosm + (size_t)b * ld;
+  const float zt = here ? margin_fwd(row[y], m, nullptr) * m.s : 0.f;
+  float mx = -3.0e38f, sm = 0.f;
+  int am = 0x7fffffff;
+  for (int c = tid * 4; c < C; c += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(row + c);
+    const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (c + e < C) {
+        const float z = (here && c + e == y) ? zt : a[e] * m.s;
+        if (z > mx) { sm = sm * __expf(mx - z) + 1.0f; mx = z; am = c + e; }
+        else sm += __expf(z - mx);
+      }
+    }
+  }
+  block_reduce_ms(mx, sm, am, sh_f, sh_i);
+  if (tid == 0) {
+    float* o = stats + (size_t)b * 4;
+    o[0] = mx; o[1] = sm; o[2] = zt; o[3] = here ? 1.f : 0.f;
+    arg[b] = c0 + am;
+  }
+}
+
+// dcos[b, c] = gscale[b] * s * (target ? slope : 1) * (exp(z - lse[b]) - [target])  for the local columns; bf16 [B, ld], pad zeroed
+__global__ __launch_bounds__(256) void arcface_dcos_lse_kernel(const float* cosm, int ld, const int64_t* label, const float* lse,
+                                                               const float* gscale, bf16* dcos, int C, long long c0, Margin m) {
+  const int b = blockIdx.y;
+  const int64_t y = label[b] - c0;
+  const bool here = y >= 0 && y < C;
+  const float* row = cosm + (size_t)b * ld;
+  float zt = 0.f, slope = 1.f;
+  if (here) zt = margin_fwd(row[y], m, &slope) * m.s;
+  const float L = lse[b], gs = gscale[b] * m.s;
+  bf16* drow = dcos + (size_t)b * ld;
+  for (int c = (blockIdx.x * 256 + threadIdx.x) * 4; c < ld; c += gridDim.x * 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(row + c);
+    const float a[4] = {v.x, v.y, v.z, v.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (c + e < C) {
+        const bool tgt = here && (c + e == y);
+        const float z = tgt ? zt : a[e] * m.s;
+        o[e] = (__expf(z - L) - (tgt ? 1.0f : 0.0f)) * gs * (tgt ? slope : 1.0f);
+      } else o[e] = 0.f;
+    }
+    bf4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+    *reinterpret_cast<bf4*>(drow + c) = ob;
+  }
+}
+
 // dcos = dlogits * s * (target ? slope(cos) : 1)   -> bf16 [B, ld] with zeroed pad
 __global__ __launch_bounds__(256) void dlogits_to_dcos_kernel(const float* dlogits, int ld_dl, const float* cosm, int ld,
                                                               const int64_t* label, bf16* dcos, int C, Margin m) {
@@ -300,6 +368,28 @@ extern "C" int mmsim_arcface_dlogits_to_dcos(const float* dlogits, int ld_dl, co
   hipLaunchKernelGGL(dlogits_to_dcos_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, dlogits, ld_dl, cosm, ld,
                      (const int64_t*)label, (bf16*)dcos, C, mk_margin(s, m, easy_margin));
   return mmsim_check_launch("dlogits_to_dcos");
+}
+
+extern "C" int mmsim_arcface_ce_partial(const float* cosm, int ld, const long long* label, float* stats, long long* arg, int B,
+                                        int C_local, long long class_offset, long long C_total, float s, float m, int easy_margin,
+                                        int* err_flag, void* stream) {
+  MMSIM_REQUIRE(cosm && label && stats && arg && err_flag && B > 0 && C_local > 0, "arcface_ce_partial: bad arguments");
+  MMSIM_REQUIRE(ld % 8 == 0 && ld >= C_local, "arcface_ce_partial: ld must be a multiple of 8 and >= C_local");
+  MMSIM_REQUIRE(class_offset >= 0 && class_offset + C_local <= C_total, "arcface_ce_partial: shard outside [0, C_total)");
+  hipLaunchKernelGGL(arcface_ce_partial_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, cosm, ld, (const int64_t*)label, stats,
+                     arg, C_local, class_offset, C_total, mk_margin(s, m, easy_margin), err_flag);
+  return mmsim_check_launch("arcface_ce_partial");
+}
+
+extern "C" int mmsim_arcface_dcos_from_lse(const float* cosm, int ld, const long long* label, const float* lse,
+                                           const float* row_scale, void* dcos, int B, int C_local, long long class_offset, float s,
+                                           float m, int easy_margin, void* stream) {
+  MMSIM_REQUIRE(cosm && label && lse && row_scale && dcos && B > 0 && C_local > 0, "arcface_dcos_from_lse: bad arguments");
+  MMSIM_REQUIRE(ld % 8 == 0 && ld >= C_local, "arcface_dcos_from_lse: ld must be a multiple of 8 and >= C_local");
+  int gx = (ld + 1023) / 1024; if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(arcface_dcos_lse_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, cosm, ld, (const int64_t*)label, lse,
+                     row_scale, (bf16*)dcos, C_local, class_offset, mk_margin(s, m, easy_margin));
+  return mmsim_check_launch("arcface_dcos_from_lse");
 }
 
 // rowvec[c] = inv_w[c], rowvec[C + c] = sum_b dcos[b][c] * cos[b][c]  ( = w_hat_c . dW_hat_c, because cos = x_hat W_hat^T and

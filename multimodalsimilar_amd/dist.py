@@ -16,7 +16,7 @@ from .optim import collect_flat_buffers
 
 class GradientExchange:
     def __init__(self, modules, bucket_bytes=64 << 20, process_group=None):
-        self.flats = collect_flat_buffers(modules)
+        self.flats = collect_flat_buffers(modules, dp_only=True)
         self.bucket_bytes = bucket_bytes
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -26,7 +26,7 @@ class GradientExchange:
         roots = [modules] if isinstance(modules, torch.nn.Module) else list(modules)
         for root in roots:
             for m in root.modules():
-                if hasattr(m, "grad_ready_hook") and hasattr(m, "flat_buffers"):
+                if hasattr(m, "grad_ready_hook") and hasattr(m, "flat_buffers") and getattr(m, "dp_exchange", True):
                     m.grad_ready_hook = self._on_ready
 
     @property

@@ -12,14 +12,16 @@ import torch
 from . import ops
 
 
-def collect_flat_buffers(modules):
+def collect_flat_buffers(modules, dp_only=False):
+    """Flat parameter buffers under the modules.  dp_only: leave out modules whose gradient is NOT exchanged between data-parallel
+    ranks (``dp_exchange = False``: the class-sharded head, whose shard gradient is complete on its owner)."""
     if isinstance(modules, torch.nn.Module):
         modules = [modules]
     seen, out = set(), []
     for root in modules:
         for m in root.modules():
             fb = getattr(m, "flat_buffers", None)
-            if fb is None:
+            if fb is None or (dp_only and not getattr(m, "dp_exchange", True)):
                 continue
             for f in fb():
                 if id(f) not in seen:

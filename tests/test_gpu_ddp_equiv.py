@@ -22,13 +22,18 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+def _worker(rank, world, port, out, backend):
+    dev = rank if backend == "nccl" else 0
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(dev),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from multimodalsimilar_amd import train as T
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":      # RCCL over xGMI, one process per GPU: the production exchange (async all-reduce of ranges written on
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))      # tower side streams)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     model = T.build_model(CFG, "cuda", seed=0, dropout=False)
     ts = T.TrainStep(model, "nlp", 10)
     assert ts.exchange is not None and ts.exchange.world == 2
@@ -43,10 +48,13 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process_on_the_whole_batch(tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_ranks_equal_one_process_on_the_whole_batch(tmp_path, backend):
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank: fewer than 2 devices visible on this box")
     from multimodalsimilar_amd import train as T
     out = str(tmp_path / "ddp.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, backend), nprocs=2, join=True)
     ddp = torch.load(out)
     model = T.build_model(CFG, "cuda", seed=0, dropout=False)
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
