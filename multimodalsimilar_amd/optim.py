@@ -125,3 +125,16 @@ class FusedAdamW(torch.optim.Optimizer):
             if mv[0].numel() != f.master.numel():
                 raise ValueError("FusedAdamW.load_state_dict: moment buffer size does not match the flat parameter buffer")
             self._mv[id(f)] = tuple(t.to(device=f.master.device, dtype=torch.float32).clone() for t in mv)
+
+
+class FusedAdam(FusedAdamW):
+    """``torch.optim.Adam`` with its defaults (betas 0.9 / 0.999, eps 1e-8, weight_decay 0) on the fused flat-buffer kernel --
+    the optimiser of the reference's image-only loop (``torch.optim.Adam(model.parameters(), lr=1e-3)``,
+    cv_classifier_train_daodian.py:264).  With weight_decay = 0 Adam and AdamW are the same update, so this is the AdamW launch
+    with the decay term switched off; torch's coupled L2 form (weight_decay > 0 added to the gradient) is not implemented and
+    is refused rather than silently replaced by the decoupled one."""
+
+    def __init__(self, modules, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, exclude=()):
+        if weight_decay != 0.0:
+            raise ValueError("FusedAdam: coupled (L2) weight decay is not implemented; use FusedAdamW for decoupled decay")
+        super().__init__(modules, lr=lr, betas=betas, eps=eps, weight_decay=0.0, grad_scale=grad_scale, exclude=exclude)

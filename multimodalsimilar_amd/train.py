@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 from .bert import BertConfig, BertModel
 from .dist import GradientExchange
-from .optim import FusedAdamW, linear_schedule_lr
+from .optim import FusedAdam, FusedAdamW, linear_schedule_lr
 
 VOCAB = 21128          # hfl/chinese-roberta-wwm-ext(-large)
 
@@ -183,3 +183,55 @@ class TrainStep:
         self.t += 1
         self._set_lr()                          # lr_scheduler_emb.step(); lr_scheduler_fc.step()
         return loss.detach(), pred
+
+
+class CvTrainLoop:
+    """The reference's image-only training loop around a ``CvClassifier`` (cv_classifier_train_daodian.py):
+
+        optimizer = torch.optim.Adam(model.parameters(), lr=1e-3)                                   (:264)
+        scheduler = CosineAnnealingWarmRestarts(optimizer, T_0=7, T_mult=1, eta_min=1e-6)           (:267)
+        per step :  optimizer.zero_grad(); output = model(images, targets); loss = CE(output, targets);
+                    loss.backward(); optimizer.step()                                               (:108-142)
+        per epoch:  scheduler.step()  (:139);  model.classifier.update_m(0.04)                      (:292)
+
+    ONE optimiser over every parameter (backbone, fc / bn top and the ArcFace head), as ``model.parameters()`` is there.  The
+    scheduler is torch's own object driving the fused optimiser's param group; the margin is a kernel argument, so annealing it
+    costs nothing (no rebuild, no recompilation).  Under data parallelism gradients are exchanged as in TrainStep."""
+
+    def __init__(self, model, lr=1e-3, T_0=7, T_mult=1, eta_min=1e-6, margin_step=0.04, fused_loss=True):
+        self.model, self.fused_loss, self.margin_step = model, fused_loss, margin_step
+        self.exchange = GradientExchange(model) if dist.is_initialized() and dist.get_world_size() > 1 else None
+        gs = self.exchange.grad_scale if self.exchange else 1.0
+        self.optimizer = FusedAdam(model, lr=lr, grad_scale=gs)
+        self.scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(self.optimizer, T_0=T_0, T_mult=T_mult, eta_min=eta_min)
+        self.ce = torch.nn.CrossEntropyLoss()
+        self.epoch = 0
+
+    def step(self, batch):
+        """One training step; returns (loss, argmax of the margin logits) on the device."""
+        model = self.model
+        model.train()
+        self.optimizer.zero_grad()
+        if self.fused_loss:
+            loss, pred = model.forward_loss(batch["img_tensor"], batch["labels"])
+        else:
+            output = model(batch["img_tensor"], batch["labels"])
+            loss = self.ce(output, batch["labels"])
+            pred = torch.argmax(output, 1)
+        loss.backward()
+        if self.exchange:
+            self.exchange.finish()
+        self.optimizer.step()
+        return loss.detach(), pred
+
+    def end_epoch(self):
+        self.scheduler.step()                              # :139
+        self.model.classifier.update_m(self.margin_step)   # :292
+        self.epoch += 1
+
+    def evaluate(self, batch):
+        """Validation step (:146-170): cosine logits (``is_test=True``), their argmax and the cross-entropy the loop logs."""
+        self.model.eval()
+        with torch.no_grad():
+            output = self.model(batch["img_tensor"], batch["labels"], is_test=True)
+            return self.ce(output, batch["labels"]), torch.argmax(output, 1)

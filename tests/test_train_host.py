@@ -97,3 +97,33 @@ def test_as_native_copies_every_weight_of_an_hf_bert_model():
         assert torch.equal(nsd[k], v), k
     assert native.config.num_attention_heads == 2 and native.config.layer_norm_eps == cfg.layer_norm_eps
     assert as_native(native) is native
+
+
+def test_cv_loop_schedule_and_margin_annealing_follow_the_reference_objects():
+    """The image-only loop's lr (per epoch) is torch's CosineAnnealingWarmRestarts(T_0=7, eta_min=1e-6) on Adam(lr=1e-3) and the
+    margin grows by 0.04 per epoch, clamped as ArcMarginProduct.update_m clamps it (cv_classifier_train_daodian.py:264-267,292;
+    arcface.py:35-42)."""
+    import math
+    from multimodalsimilar_amd import train as T
+    cfg = dict(kind="cv", image="efficientnet_b0", res=64, batch=4, classes=32, fc_dim=64, use_fc=True)
+    model = T.build_model(cfg, "cpu", seed=0)
+    loop = T.CvTrainLoop(model)
+    p = torch.nn.Parameter(torch.zeros(2))
+    ref_opt = torch.optim.Adam([p], lr=1e-3)
+    ref_sched = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(ref_opt, T_0=7, T_mult=1, eta_min=1e-6, last_epoch=-1)
+    g = loop.optimizer.param_groups[0]
+    assert g["weight_decay"] == 0.0 and g["betas"] == (0.9, 0.999) and g["eps"] == 1e-8
+    # every parameter of the model is under the ONE optimiser (model.parameters() in the reference): backbone, fc/bn top, head
+    flats = {id(f) for f in loop.optimizer.flats}
+    assert id(model.backbone._flat) in flats and id(model._flat) in flats and id(model.classifier._flat) in flats
+    m0 = model.classifier.m
+    for epoch in range(16):
+        assert abs(g["lr"] - ref_opt.param_groups[0]["lr"]) < 1e-12, epoch
+        assert abs(model.classifier.m - min(m0 + 0.04 * epoch, 1.0)) < 1e-9 or model.classifier.m <= 1.0
+        assert abs(model.classifier.cos_m - math.cos(model.classifier.m)) < 1e-12
+        ref_opt.step(); ref_sched.step()
+        loop.end_epoch()
+    assert abs(g["lr"] - ref_opt.param_groups[0]["lr"]) < 1e-12 and loop.epoch == 16
+    with pytest.raises(ValueError):
+        from multimodalsimilar_amd.optim import FusedAdam
+        FusedAdam(model, weight_decay=0.01)
