@@ -16,7 +16,12 @@ Pinning status (see DESIGN.md "Oracle"):
   * effnet_ref       - PARITY UNPINNED: the reference delegates the image tower to ``timm``,
                        which is neither vendored in the reference nor installed here, and the
                        reference's tests hold no vectors for it.  effnet_ref restates timm's
-                       published ``efficientnet_b0/b4`` architecture.
+                       published ``efficientnet_b0/b4`` architecture.  Its block
+                       definitions (op order, squeeze-excite placement and width, channel rounding, repeats,
+                       skip rule) are cross-checked to float rounding against an independent implementation that
+                       IS installed, ``transformers.models.efficientnet``, with the oracle in its
+                       ``variant(tf_same=True, bn_eps=1e-3)`` mode (tests/test_oracle_effnet_hf.py): that is
+                       the TF-port variant, not timm's numerics, so the status stays "parity unpinned".
   * search_ref       - PARITY UNPINNED: the similarity search after the model (nlp_infer.py:139-152) is ``faiss``
                        (no pinned version, not installed, no vectors in the reference's tests); restates
                        IndexFlat / METRIC_INNER_PRODUCT semantics, equal scores by ascending index.

@@ -21,6 +21,34 @@ import torch.nn.functional as F
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
+# Numerical variant of the same architecture.  The default is timm's `efficientnet_b*` (PyTorch-symmetric padding k//2, BatchNorm
+# eps 1e-5): what the reference builds.  variant(tf_same=True, bn_eps=1e-3) is the TensorFlow-port variant (stride-2 convs pad
+# (k//2 - 1, k//2) = TF "same" on even inputs, eps 1e-3) that `transformers.models.efficientnet` implements -- an INDEPENDENT
+# implementation that IS installed here, used by tests/test_oracle_effnet_hf.py to check this restatement's block definitions
+# (op order, SE placement and width, channel rounding, repeats, skip rule).  It does not pin parity with timm (PARITY UNPINNED
+# stays, see the header); it catches a wrong block.
+_VARIANT = {"tf_same": False, "bn_eps": BN_EPS}
+
+
+class variant:
+    def __init__(self, tf_same=False, bn_eps=BN_EPS):
+        self.new = {"tf_same": tf_same, "bn_eps": bn_eps}
+
+    def __enter__(self):
+        self.old = dict(_VARIANT)
+        _VARIANT.update(self.new)
+
+    def __exit__(self, *a):
+        _VARIANT.update(self.old)
+
+
+def _conv_k(x, w, stride, k, groups=1):
+    """k x k conv, padding k//2 -- or, in the tf_same variant, TF "same" padding for stride 2 (right / bottom heavier)."""
+    if _VARIANT["tf_same"] and stride == 2:
+        x = F.pad(x, (k // 2 - 1, k // 2, k // 2 - 1, k // 2))
+        return F.conv2d(x, w, None, stride=stride, padding=0, groups=groups)
+    return F.conv2d(x, w, None, stride=stride, padding=k // 2, groups=groups)
+
 # (type, repeats, kernel, stride, expand, out_channels) -- the B0 base, scaled by (width, depth)
 _BASE = [("ds", 1, 3, 1, 1, 16), ("ir", 2, 3, 2, 6, 24), ("ir", 2, 5, 2, 6, 40), ("ir", 3, 3, 2, 6, 80),
          ("ir", 3, 5, 1, 6, 112), ("ir", 4, 5, 2, 6, 192), ("ir", 1, 3, 1, 6, 320)]
@@ -113,7 +141,7 @@ def _bn(x, sd, name, training, stats=None):
     else:
         mean, var = sd[name + ".running_mean"], sd[name + ".running_var"]
     shp = [1, -1] + [1] * (x.dim() - 2)
-    return (x - mean.view(shp)) / torch.sqrt(var.view(shp) + BN_EPS) * sd[name + ".weight"].view(shp) \
+    return (x - mean.view(shp)) / torch.sqrt(var.view(shp) + _VARIANT["bn_eps"]) * sd[name + ".weight"].view(shp) \
         + sd[name + ".bias"].view(shp)
 
 
@@ -133,7 +161,7 @@ def mbconv_forward(sd, n, b, x, training=True, stats=None, e=False):
     """One DS / IR block; n = state-dict prefix of the block, b = its arch() entry."""
     sc = x
     if b["type"] == "ds":
-        x = _q(F.conv2d(x, sd[n + ".conv_dw.weight"], None, stride=b["stride"], padding=b["k"] // 2, groups=b["mid"]), e)
+        x = _q(_conv_k(x, sd[n + ".conv_dw.weight"], b["stride"], b["k"], groups=b["mid"]), e)
         x = F.silu(_bn(x, sd, n + ".bn1", training, stats))
         x = _q(_se(x, sd, n), e)
         x = _q(F.conv2d(x, _q(sd[n + ".conv_pw.weight"], e)), e)
@@ -141,7 +169,7 @@ def mbconv_forward(sd, n, b, x, training=True, stats=None, e=False):
     else:
         x = _q(F.conv2d(x, _q(sd[n + ".conv_pw.weight"], e)), e)
         x = _q(F.silu(_bn(x, sd, n + ".bn1", training, stats)), e)
-        x = _q(F.conv2d(x, sd[n + ".conv_dw.weight"], None, stride=b["stride"], padding=b["k"] // 2, groups=b["mid"]), e)
+        x = _q(_conv_k(x, sd[n + ".conv_dw.weight"], b["stride"], b["k"], groups=b["mid"]), e)
         x = F.silu(_bn(x, sd, n + ".bn2", training, stats))
         x = _q(_se(x, sd, n), e)
         x = _q(F.conv2d(x, _q(sd[n + ".conv_pwl.weight"], e)), e)
@@ -160,7 +188,7 @@ def backbone_forward(sd, model_name, x, training=True, stats=None, taps=None, em
     a = arch(model_name)
     p = "backbone."
     e = emulate_bf16
-    x = _q(F.conv2d(x, sd[p + "conv_stem.weight"], None, stride=2, padding=1), e)
+    x = _q(_conv_k(x, sd[p + "conv_stem.weight"], 2, 3), e)
     x = _q(F.silu(_bn(x, sd, p + "bn1", training, stats)), e)
     if taps is not None:
         taps["stem"] = x

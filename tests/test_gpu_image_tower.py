@@ -434,9 +434,13 @@ def test_cv_classifier_matches_oracle(name, use_fc):
     print(f"\n[{name}] emb L2 err {e:.4f} (bf16-emulation envelope d0 {d0:.4f}); loss {loss.item():.4f} vs {loss_ref:.4f}; "
           f"grad L2 median {ge[len(ge) // 2]:.3f} (envelope {g0[len(g0) // 2]:.3f}) over {len(keys)} tensors")
     assert len(keys) > 50
-    assert e < 1.5 * d0 + 0.02
-    assert abs(loss.item() - loss_ref) < 1e-2 * loss_ref + 1.5 * abs(loss_emu - loss_ref)
-    assert ge[len(ge) // 2] < 1.5 * g0[len(g0) // 2] + 0.03
+    # RANDOM-INIT smoke (ill-conditioned on purpose: ~50-100 train-mode BatchNorms at init amplify every rounding).  The tight
+    # whole-tower checks are in tests/test_gpu_eval_parity.py (conditioned weights, eval and train mode); here the HIP path must
+    # stay inside the envelope the oracle itself spans when only its STORED tensors are rounded to bf16 (factor 1.35, as there),
+    # and the loss within 1e-2 plus the oracle's own loss displacement under that emulation (factor 1).
+    assert e < 1.35 * d0 + 0.01
+    assert abs(loss.item() - loss_ref) < 1e-2 * loss_ref + abs(loss_emu - loss_ref)
+    assert ge[len(ge) // 2] < 1.35 * g0[len(g0) // 2] + 0.02
     # running statistics follow torch semantics (momentum 0.1, unbiased variance); two forward passes were run
     stats = {}
     effnet_ref.cv_predict_emb(sd, name, x, use_fc=use_fc, training=True, stats=stats)
