@@ -24,6 +24,12 @@ extern "C" {
 int mmsim_version(void);
 int mmsim_device_count(void);
 const char* mmsim_last_error(void);
+/* Deterministic (verification) mode, process-wide: every cross-workgroup sum in a fixed order (partial slabs reduced by one
+ * workgroup per output, no split-K, single-slice pooling, serial embedding scatter).  Results are then bit-identical from run
+ * to run; the default mode keeps the faster forms whose fp32 atomic adds arrive in varying order.  Costs step time. */
+int mmsim_set_deterministic(int on);
+int mmsim_get_deterministic(void);
+
 
 /* ---- dense products: torch F.linear / nn.Linear / 1x1 conv and their backward -------------------
  * C[M,N] = alpha * op(A)[M,K] op(B)[K,N] (+bias[N]) with a fused epilogue, bf16 inputs, fp32 accumulate.
@@ -262,7 +268,8 @@ int mmsim_pw_expand_bwd(const void* dpre, const void* z1, const void* x, const v
 /* Stem: 3x3 stride-2 pad-1 conv on the NCHW fp32 image -> NHWC bf16, with the output's BN sums; and its wgrad. */
 int mmsim_stem_fwd(const float* x, const float* w, void* z, float* sums, int B, int Hi, int Wi, int Co, float* scratch,
                    unsigned long long scratch_floats, void* stream);
-int mmsim_stem_wgrad(const void* dz, const float* x, float* dw, int B, int Hi, int Wi, int Co, void* stream);
+int mmsim_stem_wgrad(const void* dz, const float* x, float* dw, int B, int Hi, int Wi, int Co, float* scratch,
+                     unsigned long long scratch_floats, void* stream);
 /* Tower top (cv_classifier.py:50-54): dropout -> bf16, BatchNorm1d on fp32 [B,C], pool backward broadcast. */
 int mmsim_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                    float* run_mean, float* run_var, int B, int C, float eps, float momentum, int training, void* stream);

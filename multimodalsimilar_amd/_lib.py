@@ -80,7 +80,7 @@ class _Lib:
 
         def call(*args):
             rc = fn(*args)
-            if restype is ctypes.c_int and name not in ("version", "device_count", "pw_expand_bwd_eligible") and rc != 0:
+            if restype is ctypes.c_int and name not in ("version", "device_count", "pw_expand_bwd_eligible", "get_deterministic") and rc != 0:
                 raise MmsimError(f"{full}: {self.last_error()} (code {rc})")
             return rc
         object.__setattr__(self, name, call)

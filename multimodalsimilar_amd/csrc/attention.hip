@@ -165,12 +165,14 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
   char* Ds = Ks + S * ROW_PITCH;            // dS^T [S keys][DST_PITCH] for the current query tile
   float* fl = reinterpret_cast<float*>(Ds + S * DST_PITCH);
   float* lse = fl; float* dlt = fl + S; float* mb = fl + S + 64;     // dlt: [2][32] delta of the staged tiles
-  float* cb = fl + 2 * S + 64;              // [192] column sums of this (b, h)'s dq | dk | dv (bias gradient of the QKV projection)
+  float* cb = fl + 2 * S + 64;              // [NT][192] column sums of this (b, h)'s dq | dk | dv (bias gradient of the QKV projection),
+                                            // one slot per wave: each wave adds into its own in program order, the slots are summed in wave order
+                                            // (LDS float atomics from several waves arrive in varying order: last-bit run-to-run differences)
   float cq[TPW][4];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) cq[t][0] = cq[t][1] = cq[t][2] = cq[t][3] = 0.f;
   if (p.dbias_parts)
-    for (int i = threadIdx.x; i < 192; i += NTHR) cb[i] = 0.f;       // ordered before the adds by the barriers of the loop
+    for (int i = threadIdx.x; i < 192 * NT; i += NTHR) cb[i] = 0.f;       // ordered before the adds by the barriers of the loop
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5;
   const int bh = blockIdx.x, b = bh / p.heads, h = bh % p.heads;
   const bf16* base = p.qkv + (size_t)b * S * p.ld_qkv + h * 64;
@@ -360,8 +362,8 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
       sk += bf2f(*reinterpret_cast<const bf16*>(dKs + (k0 + r) * ROW_PITCH + d * 2));
       sv += bf2f(*reinterpret_cast<const bf16*>(dVs + (k0 + r) * ROW_PITCH + d * 2));
     }
-    atomicAdd(cb + 64 + d, sk);
-    atomicAdd(cb + 128 + d, sv);
+    cb[192 * w + 64 + d] += sk;            // this wave's slot: lane d is the only writer of column d
+    cb[192 * w + 128 + d] += sv;
   }
   if (p.dbias_parts) {
 #pragma unroll
@@ -372,12 +374,16 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
         float sq = cq[t][e];
 #pragma unroll
         for (int o2 = 1; o2 < 16; o2 <<= 1) sq += __shfl_xor(sq, o2, 64);
-        if ((lane & 15) == 0) atomicAdd(cb + 16 * d4 + (lane >> 4) * 4 + e, sq);
+        if ((lane & 15) == 0) cb[192 * w + 16 * d4 + (lane >> 4) * 4 + e] += sq;      // same lane for a repeated d4: program order
       }
     }
     __syncthreads();
-    for (int i = tid; i < 192; i += 64 * NT)
-      p.dbias_parts[(size_t)b * 3 * p.H + (i >> 6) * p.H + h * 64 + (i & 63)] = cb[i];
+    for (int i = tid; i < 192; i += 64 * NT) {
+      float t = cb[i];
+#pragma unroll
+      for (int ww = 1; ww < NT; ++ww) t += cb[192 * ww + i];
+      p.dbias_parts[(size_t)b * 3 * p.H + (i >> 6) * p.H + h * 64 + (i & 63)] = t;
+    }
   }
 }
 
@@ -414,7 +420,7 @@ extern "C" int mmsim_attn_fwd(const void* qkv, int ld_qkv, const long long* mask
 }
 
 static size_t attn_bwd_lds(int S) {      // Q / dO tile pairs + K image + dS^T image + lse[S], delta[2][32], mask[S], bias sums[192]
-  return (size_t)4 * 32 * ROW_PITCH + (size_t)S * (ROW_PITCH + DST_PITCH) + (size_t)(2 * S + 64 + 192) * 4;
+  return (size_t)4 * 32 * ROW_PITCH + (size_t)S * (ROW_PITCH + DST_PITCH) + (size_t)(2 * S + 64 + 192 * (S / 32)) * 4;      // bias sums: one [192] slot per wave
 }
 
 static int attn_bwd_impl(const void* qkv, int ld_qkv, const long long* mask, const void* ctx, const void* dctx, int ld_ctx,

@@ -20,6 +20,7 @@ typedef __attribute__((ext_vector_type(8))) short s8;
 extern "C" void mmsim_set_error(const char* msg);
 int mmsim_check_launch(const char* what);
 int mmsim_current_device(void);
+int mmsim_deterministic(void);      // core.hip: fixed-order reductions everywhere (verification mode)
 
 #define MMSIM_REQUIRE(cond, msg)                 \
   do {                                           \

@@ -94,6 +94,7 @@ __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
 
 // out[i] += sum_p parts[p*n + i].  Block = 64 outputs x 4 waves; the part range is strided over (gridDim.y x 4) waves,
 // reduced across the block's waves in LDS, and leaves as ONE atomic per output per block (gridDim.y <= 8 adders).
+template <bool ATOMIC>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ parts, int nparts, int n, float* out) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -107,7 +108,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
   red[wv][lane] = a0 + a1;
   __syncthreads();
-  if (wv == 0 && i < n) atomicAdd(out + i, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+  if (wv == 0 && i < n) {
+    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (ATOMIC) atomicAdd(out + i, t);
+    else out[i] += t;          // gridDim.y == 1: the only adder of this output, parts summed in a fixed order
+  }
 }
 void mmsim_launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s);
 static void launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s) {
@@ -116,7 +121,11 @@ static void launch_reduce(const float* parts, int nparts, int n, float* out, int
 void mmsim_launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s) {
   if (!accumulate) (void)hipMemsetAsync(out, 0, (size_t)n * sizeof(float), s);
   int gy = nparts / 16; if (gy > 8) gy = 8; if (gy < 1) gy = 1;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 63) / 64, gy), dim3(256), 0, s, parts, nparts, n, out);
+  if (mmsim_deterministic()) {
+    hipLaunchKernelGGL(reduce_partials_kernel<false>, dim3((n + 63) / 64, 1), dim3(256), 0, s, parts, nparts, n, out);
+    return;
+  }
+  hipLaunchKernelGGL(reduce_partials_kernel<true>, dim3((n + 63) / 64, gy), dim3(256), 0, s, parts, nparts, n, out);
 }
 
 // ------------------------------------------------------------------ BN statistics
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(64) void se_wgrad_kernel(const float* __restrict__ 
                                                       int B, int C, int R) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   const int r0 = blockIdx.y * 16;
-  const int bq = (B + 3) / 4, b0 = blockIdx.z * bq, b1 = min(B, b0 + bq);
+  const int bq = (B + (int)gridDim.z - 1) / (int)gridDim.z, b0 = blockIdx.z * bq, b1 = min(B, b0 + bq);
   const bool cok = c < C;
   const int cc = min(c, C - 1);
   __shared__ float hsl[64][16], drl[64][16];      // this block's 16 hidden units of hs / dr for 64 batch rows (zero padded)
@@ -962,7 +971,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
 // ([32 taps][32 pixels] bf16: row reads are the first operand) and its dz rows pixel-major ([32 pixels][Co]: the second operand
 // through the transposing read), so dz is read from HBM once (the VALU version re-read every dz row once per tap).
 template <int CT>
-__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const bf16* __restrict__ dz, const float* __restrict__ x, float* dw, StemGeom g,
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const bf16* __restrict__ dz, const float* __restrict__ x, float* parts, StemGeom g,
                                                               int pix_per_block) {
   constexpr int XP = 80, ZP = 144;             // row pitches in bytes: 32 pixels (64 B) + pad; <= 64 channels (128 B) + pad
   __shared__ __attribute__((aligned(16))) char xs_all[4][2 * 32 * XP];       // bf16 hi image, then the lo image (x = hi + lo: fp32-accurate)
@@ -1034,17 +1043,22 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const bf16* __rest
     }
     __syncthreads();
   }
-  // acc[tt][ct][e] = D[tap 16tt + 4kg + e][co 16ct + (lane & 15)]: block sum in LDS, then one atomic per weight per block
+  // acc[tt][ct][e] = D[tap 16tt + 4kg + e][co 16ct + (lane & 15)]: the four waves' sums are added in wave order through LDS (no
+  // atomics: their arrival order would change the last bit), then one partial-slab row per block [27 * Co]
+  for (int wq = 0; wq < 4; ++wq) {
+    if (wv == wq) {
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
+      for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(red + (16 * tt + 4 * kg + e) * 64 + 16 * ct + (lane & 15), acc[tt][ct][e]);
-  __syncthreads();
+          for (int e = 0; e < 4; ++e) red[(16 * tt + 4 * kg + e) * 64 + 16 * ct + (lane & 15)] += acc[tt][ct][e];
+    }
+    __syncthreads();
+  }
   for (int i = tid; i < 27 * g.Co; i += 256) {
     const int co = i / 27, tap = i - co * 27;
-    atomicAdd(dw + i, red[tap * 64 + co]);
+    parts[(size_t)blockIdx.x * 27 * g.Co + i] = red[tap * 64 + co];
   }
 }
 
@@ -1163,7 +1177,7 @@ static int pool_bn_act_impl(const void* z, const float* scale, const float* shif
   // large feature maps: split the HW range over blockIdx.z so that more than B blocks stream (few adders per output)
   int nz = 1;
   const int nr = pool_nr(C), gy = pool_grid_y(C);
-  while (nz < 16 && HW / (nz * 2 * nr) >= 16 && B * gy * nz < 2048) nz *= 2;      // >= 16 rows per row lane and z-slice: a slice costs 8 C atomics
+  while (!mmsim_deterministic() && nz < 16 && HW / (nz * 2 * nr) >= 16 && B * gy * nz < 2048) nz *= 2;      // >= 16 rows per row lane and z-slice: a slice costs 8 C atomics
   const int rpz = (HW + nz - 1) / nz;
   if (nz > 1) (void)hipMemsetAsync(out, 0, (size_t)B * C * sizeof(float), (hipStream_t)stream);
   hipLaunchKernelGGL(pool_bn_act_kernel, dim3(B, gy, nz), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scale, shift,
@@ -1188,7 +1202,7 @@ extern "C" int mmsim_pool_bn_bwd(const void* z, const float* scale, const float*
   MMSIM_REQUIRE(z && scale && shift && mean && rstd && dy && out5 && B > 0 && HW > 0, "pool_bn_bwd: bad arguments"); REQ_C8(C, "pool_bn_bwd");
   const int nr = pool_nr(C), gy = pool_grid_y(C);
   int nz = 1;
-  while (nz < 16 && HW / (nz * 2 * nr) >= 16 && B * gy * nz < 2048) nz *= 2;
+  while (!mmsim_deterministic() && nz < 16 && HW / (nz * 2 * nr) >= 16 && B * gy * nz < 2048) nz *= 2;
   const int rpz = (HW + nz - 1) / nz;
   if (nz > 1) (void)hipMemsetAsync(out5, 0, (size_t)5 * B * C * sizeof(float), (hipStream_t)stream);
   hipLaunchKernelGGL(pool_bn_bwd_kernel, dim3(B, gy, nz), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scale, shift,
@@ -1199,7 +1213,7 @@ extern "C" int mmsim_pool_bn_bwd(const void* z, const float* scale, const float*
 extern "C" int mmsim_bn_bwd_sums_from_pool(const float* out5, const float* gate, const float* dsq, float* sums, int B, int HW,
                                            int C, void* stream) {
   MMSIM_REQUIRE(out5 && gate && dsq && sums && B > 0 && HW > 0 && C > 0, "bn_bwd_sums_from_pool: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_sums_from_pool_kernel, dim3((C + 63) / 64, B >= 64 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, out5, gate, dsq, sums, B, C,
+  hipLaunchKernelGGL(bn_bwd_sums_from_pool_kernel, dim3((C + 63) / 64, (B >= 64 && !mmsim_deterministic()) ? 8 : 1), dim3(256), 0, (hipStream_t)stream, out5, gate, dsq, sums, B, C,
                      1.0f / (float)HW);
   return mmsim_check_launch("bn_bwd_sums_from_pool");
 }
@@ -1233,7 +1247,7 @@ extern "C" int mmsim_se_mlp_bwd(const float* dgate, const float* gate, const flo
   hipLaunchKernelGGL(se_colmix_kernel, dim3((C + 63) / 64, (B + 3) / 4), dim3(256), 0, st, w_reduce, dr, (const float*)nullptr, ds, B, C, RD,
                      SE_PRE_NONE, SE_POST_NONE);
   (void)hipMemsetAsync(dweT, 0, (size_t)C * RD * sizeof(float), st);
-  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 63) / 64, (RD + 15) / 16, 4), dim3(64), 0, st, dgate, gate, dr, hs, s, dw_reduce, db_reduce,
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 63) / 64, (RD + 15) / 16, mmsim_deterministic() ? 1 : 4), dim3(64), 0, st, dgate, gate, dr, hs, s, dw_reduce, db_reduce,
                      dweT, db_expand, B, C, RD);
   hipLaunchKernelGGL(se_transpose_kernel, dim3((C * RD + 255) / 256), dim3(256), 0, st, dweT, dw_expand, RD, C, 1);
   return mmsim_check_launch("se_mlp_bwd");
@@ -1364,18 +1378,21 @@ extern "C" int mmsim_stem_fwd(const float* x, const float* w, void* z, float* su
   return mmsim_check_launch("stem_fwd");
 }
 
-extern "C" int mmsim_stem_wgrad(const void* dz, const float* x, float* dw, int B, int Hi, int Wi, int Co, void* stream) {
+extern "C" int mmsim_stem_wgrad(const void* dz, const float* x, float* dw, int B, int Hi, int Wi, int Co, float* scratch,
+                                unsigned long long scratch_floats, void* stream) {
   MMSIM_REQUIRE(dz && x && dw && B > 0, "stem_wgrad: bad arguments"); REQ_C8(Co, "stem_wgrad");
   MMSIM_REQUIRE(Co <= 64, "stem_wgrad: at most 64 output channels");
   StemGeom g; g.B = B; g.Hi = Hi; g.Wi = Wi; g.Ho = (Hi + 2 - 3) / 2 + 1; g.Wo = (Wi + 2 - 3) / 2 + 1; g.Co = Co; g.d_wo = make_fastdiv(g.Wo); g.d_ho = make_fastdiv(g.Ho);
   const int npix = B * g.Ho * g.Wo;
-  const int ppb = ((npix + 511) / 512 + 127) / 128 * 128;         // <= 512 blocks (each ends in 27*Co atomics), whole 4-wave x 32-pixel trips
+  const int ppb = ((npix + 511) / 512 + 127) / 128 * 128;         // <= 512 blocks (one slab row each), whole 4-wave x 32-pixel trips
   const dim3 grid((npix + ppb - 1) / ppb), block(256);
+  REQ_SCRATCH((size_t)grid.x * 27 * Co, "stem_wgrad");
   const int CT = (Co + 15) / 16;
-  if (CT == 1) hipLaunchKernelGGL((stem_wgrad_mfma_kernel<1>), grid, block, 0, (hipStream_t)stream, (const bf16*)dz, x, dw, g, ppb);
-  else if (CT == 2) hipLaunchKernelGGL((stem_wgrad_mfma_kernel<2>), grid, block, 0, (hipStream_t)stream, (const bf16*)dz, x, dw, g, ppb);
-  else if (CT == 3) hipLaunchKernelGGL((stem_wgrad_mfma_kernel<3>), grid, block, 0, (hipStream_t)stream, (const bf16*)dz, x, dw, g, ppb);
-  else hipLaunchKernelGGL((stem_wgrad_mfma_kernel<4>), grid, block, 0, (hipStream_t)stream, (const bf16*)dz, x, dw, g, ppb);
+  if (CT == 1) hipLaunchKernelGGL((stem_wgrad_mfma_kernel<1>), grid, block, 0, (hipStream_t)stream, (const bf16*)dz, x, scratch, g, ppb);
+  else if (CT == 2) hipLaunchKernelGGL((stem_wgrad_mfma_kernel<2>), grid, block, 0, (hipStream_t)stream, (const bf16*)dz, x, scratch, g, ppb);
+  else if (CT == 3) hipLaunchKernelGGL((stem_wgrad_mfma_kernel<3>), grid, block, 0, (hipStream_t)stream, (const bf16*)dz, x, scratch, g, ppb);
+  else hipLaunchKernelGGL((stem_wgrad_mfma_kernel<4>), grid, block, 0, (hipStream_t)stream, (const bf16*)dz, x, scratch, g, ppb);
+  launch_reduce(scratch, grid.x, 27 * Co, dw, 1, (hipStream_t)stream);      /* dw += */
   return mmsim_check_launch("stem_wgrad");
 }
 

@@ -29,6 +29,16 @@ int mmsim_current_device(void) {
   return d;
 }
 
+// Deterministic mode (verification): every cross-workgroup sum is formed in a fixed order -- reductions of partial slabs by ONE
+// workgroup per output without atomics, no split-K (one adder per output element), one z-slice in the pooling kernels, a
+// serial embedding scatter.  Results are then bit-identical from run to run (tests/test_gpu_determinism.py); the default mode
+// keeps the faster forms whose fp32 atomic adds arrive in varying order (last-bit differences that train-mode BatchNorm at
+// random init amplifies: see DESIGN.md section 5).
+static int g_deterministic = 0;
+extern "C" int mmsim_set_deterministic(int on) { g_deterministic = on ? 1 : 0; return MMSIM_OK; }
+extern "C" int mmsim_get_deterministic(void) { return g_deterministic; }
+int mmsim_deterministic(void) { return g_deterministic; }
+
 extern "C" int mmsim_version(void) { return 200; }
 
 // Returns the number of visible HIP devices, or -1 with the error string set.

@@ -261,6 +261,7 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   MMSIM_REQUIRE(!(epilogue == EPI_MUL_GELU_GRAD || epilogue == EPI_ADD || epilogue == EPI_MUL) || aux_in, "gemm: epilogue needs aux_in");
   MMSIM_REQUIRE(epilogue == EPI_NONE || (ld_aux % 4) == 0 || epilogue == EPI_TANH, "gemm: ld_aux must be a multiple of 4");
   MMSIM_REQUIRE(split_k >= 1, "gemm: split_k >= 1");
+  if (mmsim_deterministic()) split_k = 1;          // one adder per output element: the "atomic" epilogue is then order-free
   MMSIM_REQUIRE(split_k == 1 || (c_is_f32 && epilogue == EPI_NONE), "gemm: split-K needs f32 output and no epilogue");
   MMSIM_REQUIRE(!accumulate || c_is_f32, "gemm: accumulate needs f32 output");
   MMSIM_REQUIRE(!accumulate || epilogue == EPI_NONE || epilogue == EPI_ROWFIX, "gemm: accumulate with this epilogue is not implemented");

@@ -438,6 +438,7 @@ extern "C" int mmsim_gemm_bf16_wgrad_pair(int M1, int M2, int N, int K, const vo
   MMSIM_REQUIRE(M1 > 0 && M2 > 0 && M1 % GBM == 0 && M2 % GBM == 0 && N > 0 && N % 256 == 0 && K > 0 && K % 64 == 0,
                 "gemm_wgrad_pair: M1, M2, N must be multiples of 256 and K of 64");
   MMSIM_REQUIRE(split_k >= 1, "gemm_wgrad_pair: split_k >= 1");
+  if (mmsim_deterministic()) split_k = 1;          // one adder per output element
   MMSIM_REQUIRE(lda1 >= M1 && lda2 >= M2 && ldb1 >= N && ldb2 >= N && ldc1 >= N && ldc2 >= N, "gemm_wgrad_pair: leading dimension too small");
   MMSIM_REQUIRE((lda1 % 8) == 0 && (lda2 % 8) == 0 && (ldb1 % 8) == 0 && (ldb2 % 8) == 0 && (ldc1 % 4) == 0 && (ldc2 % 4) == 0,
                 "gemm_wgrad_pair: lda / ldb must be multiples of 8, ldc of 4");

@@ -115,12 +115,16 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* dout, con
                                                            const float* word, const float* pos, const float* type,
                                                            const float* gamma, float* dword, float* dpos, float* dtype,
                                                            float* dgamma, float* dbeta, int B, int S, int H, float eps,
-                                                           int bchunk, Drop dr, int vocab, int tvocab, int max_pos, int* err) {
+                                                           int bchunk, Drop dr, int vocab, int tvocab, int max_pos, int* err, int serial) {
   __shared__ __attribute__((aligned(16))) float rowbuf[4][MAXC * 256];       // one d(embedding) row per wave
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int gw = blockIdx.x * 4 + wv;
   const int nchunks = (B + bchunk - 1) / bchunk;
-  if (gw >= S * nchunks) return;
+  // serial (deterministic mode): ONE wave walks every (position, batch chunk) in order, so every atomic below has a single
+  // adder issuing in program order; otherwise a wave per (position, batch chunk)
+  const int gw_first = serial ? 0 : blockIdx.x * 4 + wv, gw_last = serial ? S * nchunks : gw_first + 1;
+  if (serial ? (blockIdx.x != 0 || wv != 0) : (gw_first >= S * nchunks)) return;
+#pragma unroll 1
+  for (int gw = gw_first; gw < gw_last; ++gw) {
   const int sw = gw % S, b0 = (gw / S) * bchunk, b1 = min(B, b0 + bchunk);
   float4 apos[MAXC], at0[MAXC], at1[MAXC], ag[MAXC], ab[MAXC];
 #pragma unroll
@@ -209,6 +213,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* dout, con
       atomicAdd(a, ab[c].x); atomicAdd(a + 1, ab[c].y); atomicAdd(a + 2, ab[c].z); atomicAdd(a + 3, ab[c].w);
     }
   }
+  }
 }
 
 // ---------------------------------------------------------------- y = dropout(t) + resid ; h = LN(y)
@@ -253,6 +258,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16* t, const bf
 // branch) and dt = dropout-mask(dy) (gradient of the dense output; same buffer as dy when p == 0), plus
 // column sums: dgamma, dbeta, dbias (= colsum dt).
 // out[i] += sum_p parts[p*part_stride + i]  (64 outputs x 4 waves per block; gridDim.y part-chunks, one atomic each)
+template <bool ATOMIC>
 __global__ __launch_bounds__(256) void row_reduce_partials_kernel(const float* __restrict__ parts, int nparts, size_t part_stride,
                                                                   int n, float* out) {
   __shared__ float red[4][64];
@@ -267,7 +273,11 @@ __global__ __launch_bounds__(256) void row_reduce_partials_kernel(const float* _
   }
   red[wv][lane] = a0 + a1;
   __syncthreads();
-  if (wv == 0 && i < n) atomicAdd(out + i, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+  if (wv == 0 && i < n) {
+    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (ATOMIC) atomicAdd(out + i, t);
+    else out[i] += t;          // deterministic mode: one workgroup per output, fixed order
+  }
 }
 
 template <int NC>     // NC = ceil(H / 256) chunks per lane: keeps the per-lane column accumulators at 3*4*NC registers
@@ -573,12 +583,13 @@ extern "C" int mmsim_embed_ln_bwd(const void* dout, const long long* ids, const 
   MMSIM_REQUIRE(H % 4 == 0 && H <= 256 * MAXC, "embed_ln_bwd: H must be a multiple of 4 and <= 2048");
   MMSIM_REQUIRE(vocab_size > 0 && type_vocab_size > 0 && type_vocab_size <= 2 && max_positions > 0,
                 "embed_ln_bwd: table sizes must be positive (at most two token types)");
+  const int serial = mmsim_deterministic();
   const int bchunk = B >= 64 ? 16 : (B >= 8 ? 4 : 1);
-  const int nw = S * ((B + bchunk - 1) / bchunk);
+  const int nw = serial ? 1 : S * ((B + bchunk - 1) / bchunk);
   hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout,
                      (const int64_t*)ids, (const int64_t*)token_types, (const int64_t*)position_ids, word, pos, type, gamma, dword, dpos,
                      dtype, dgamma, dbeta, B, S, H, eps, bchunk, make_drop(dropout_p, seed, stream_id), vocab_size, type_vocab_size,
-                     max_positions, err_flag);
+                     max_positions, err_flag, serial);
   return mmsim_check_launch("embed_ln_bwd");
 }
 
@@ -623,16 +634,22 @@ extern "C" int mmsim_ln_bwd(const void* dh_a, const void* dh_b, const void* y, c
   float* outs[3] = {dgamma, dbeta, dbias};
   int gy = nblk / 16; if (gy > 8) gy = 8; if (gy < 1) gy = 1;
   for (int k = 0; k < 3; ++k)
-    if (outs[k])
-      hipLaunchKernelGGL(row_reduce_partials_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream, scratch + (size_t)k * H,
-                         nblk, (size_t)3 * H, H, outs[k]);
+    if (outs[k]) {
+      if (mmsim_deterministic())
+        hipLaunchKernelGGL(row_reduce_partials_kernel<false>, dim3((H + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream,
+                           scratch + (size_t)k * H, nblk, (size_t)3 * H, H, outs[k]);
+      else
+        hipLaunchKernelGGL(row_reduce_partials_kernel<true>, dim3((H + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream,
+                           scratch + (size_t)k * H, nblk, (size_t)3 * H, H, outs[k]);
+    }
   return mmsim_check_launch("ln_bwd");
 }
 
 extern "C" int mmsim_colsum_bf16(const void* x, int ld, float* out, int M, int N, void* stream) {
   MMSIM_REQUIRE(x && out && M > 0 && N > 0, "colsum: bad arguments");
   MMSIM_REQUIRE(ld % 8 == 0 && ld >= ((N + 7) & ~7), "colsum: ld must be a multiple of 8 covering N rounded up to 8");
-  const int rpb = M >= 8192 ? 512 : 256;      // fewer, longer blocks: every block ends in one atomic per column
+  // fewer, longer blocks: every block ends in one atomic per column.  Deterministic mode: ONE row chunk (one adder per column)
+  const int rpb = mmsim_deterministic() ? M : (M >= 8192 ? 512 : 256);
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
                      (const bf16*)x, ld, out, M, N, rpb);
   return mmsim_check_launch("colsum");

@@ -572,7 +572,7 @@ class EfficientNet(nn.Module):
         P0 = B * (st.Hi // 2) * (st.Wi // 2)
         dz0 = E(P0, a.stem)
         self._bn_bwd(st, "bn1", dx, st.z0, P0, a.stem, dz0, act=True)
-        lib.stem_wgrad(dz0.data_ptr(), st.x.data_ptr(), G("conv_stem.weight").data_ptr(), B, st.Hi, st.Wi, a.stem, s)
+        lib.stem_wgrad(dz0.data_ptr(), st.x.data_ptr(), G("conv_stem.weight").data_ptr(), B, st.Hi, st.Wi, a.stem, *self._scr(), s)
         if self.grad_ready_hook:
             self.grad_ready_hook(fl, *fl.span("conv_stem.weight", "bn1.bias"))
             self.grad_ready_hook(fl, *fl.span("conv_head.weight", "bn2.bias"))

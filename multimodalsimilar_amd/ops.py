@@ -70,6 +70,16 @@ def check_device_flags():
         raise err
 
 
+def set_deterministic(on=True):
+    """Deterministic (verification) mode of the HIP library: fixed-order reductions everywhere, no split-K.  Bit-identical
+    results from run to run at a cost in step time (mmsim_set_deterministic).  MMSIM_DETERMINISTIC=1 turns it on at import."""
+    lib.set_deterministic(int(bool(on)))
+
+
+def is_deterministic():
+    return bool(lib.get_deterministic())
+
+
 def _chk(t, dtype, name, dims=None):
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a tensor, got {type(t).__name__}")
@@ -333,3 +343,7 @@ def adamw_rows_l2norm(p2d, g2d, m2d, v2d, w_hat, inv_norm, lr, beta1, beta2, eps
         raise ValueError("adamw_rows: w_hat [R, D] contiguous and inv_norm [R] required")
     lib.adamw_rows_l2norm(_p(p2d), _p(g2d), _p(m2d), _p(v2d), _p(w_hat), _p(inv_norm), R, D, float(lr), float(beta1), float(beta2),
                           float(eps), float(weight_decay), int(step), float(grad_scale), float(l2_eps), _stream())
+
+
+if os.environ.get("MMSIM_DETERMINISTIC", "0") == "1":
+    set_deterministic(True)

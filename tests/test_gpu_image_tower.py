@@ -300,7 +300,7 @@ def test_stem_conv_and_transformed_pointwise_gemm():
     dz = nhwc(rnd(B, Co, Ho, Wo, seed=3))
     ref.backward(nchw(dz, B, Ho, Wo))
     dw = torch.zeros_like(w)
-    lib.stem_wgrad(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Co, s)
+    lib.stem_wgrad(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Co, *scr(), s)
     assert relerr(dw, wr.grad) < 2e-3
     # 1x1 conv on silu(scale*z+shift)*gate, forward and weight gradient
     P, Cin, Cout, HW = 360, 144, 40, 30

@@ -10,6 +10,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture
+def deterministic():
+    """Fixed-order reductions (mmsim_set_deterministic): the loss-curve comparisons below are then free of run-to-run noise and
+    carry the tight tolerances they had before that noise was absorbed into them."""
+    from multimodalsimilar_amd import ops
+    ops.set_deterministic(True)
+    yield
+    ops.set_deterministic(False)
+
+
 def _text_oracle(model, steps):
     from oracle import bert_ref, step_ref
     cfg = model.ptm.config
@@ -20,7 +30,7 @@ def _text_oracle(model, steps):
                                    margin=0.4)
 
 
-def test_text_tower_loss_curve_matches_oracle():
+def test_text_tower_loss_curve_matches_oracle(deterministic):
     from multimodalsimilar_amd import train as T
     cfg = dict(kind="nlp", text="tiny", seq_len=32, batch=16, classes=64)
     model = T.build_model(cfg, "cpu", seed=0, dropout=False)
@@ -38,17 +48,21 @@ def test_text_tower_loss_curve_matches_oracle():
     print("\noracle losses", [round(x, 4) for x in ref], "\nhip    losses", [round(x, 4) for x in got])
     for a, b in zip(got, ref):
         assert abs(a - b) < 1.5e-2 * abs(b)
-    # parameters after 6 AdamW steps (lr schedules included) stay together
-    # AdamW's early updates are ~lr*sign(g): an element whose gradient is ~0 may flip, so compare in the mean
+    # parameters after 6 AdamW steps (lr schedules included) stay together.  AdamW's early updates are ~lr * sign(g): an element whose
+    # bf16 / fp32 gradients straddle zero moves the other way by up to 2 lr in that step -- so the max-norm bound is Adam's own
+    # (2 x the sum of the head's learning rates so far), and what is tight is the mean and the FRACTION of elements off by > 5e-3
     w = model.classifier.weight.detach().cpu()
-    assert (w - orc.head.detach()).abs().mean() < 2e-3           # head lr warms up to 1e-2 (6 steps of <= 1e-2 each)
+    d = (w - orc.head.detach()).abs()
+    lr_sum = sum(T.linear_schedule_lr(1e-2, t, 0.15 * steps, steps) for t in range(steps))
+    assert d.mean() < 2e-3           # head lr warms up to 1e-2 (6 steps of <= 1e-2 each)
+    assert d.max() < 2 * lr_sum + 1e-3 and (d > 5e-3).float().mean() < 0.03
     k = "encoder.layer.1.output.dense.weight"
     assert (dict(model.ptm.named_parameters())[k].detach().cpu() - orc.text[k].detach()).abs().mean() < 5e-5   # lr 5e-5
     assert abs(ts.opt_fc.param_groups[0]["lr"] - orc.opt_fc.param_groups[0]["lr"]) < 1e-12
     assert abs(ts.opt_emb.param_groups[0]["lr"] - orc.opt_emb.param_groups[0]["lr"]) < 1e-12
 
 
-def test_two_tower_step_literal_and_fused_paths_agree_and_track_oracle():
+def test_two_tower_step_literal_and_fused_paths_agree_and_track_oracle(deterministic):
     from multimodalsimilar_amd import train as T
     from oracle import bert_ref, step_ref
     cfg = T.CONFIGS["tiny"]
@@ -73,10 +87,9 @@ def test_two_tower_step_literal_and_fused_paths_agree_and_track_oracle():
     ref = [orc.step(T.synthetic_batch(cfg, "cpu", seed=70 + i))[0].item() for i in range(3)]
     print("\nfused", losses[True], "\nliteral", losses[False], "\noracle", ref)
     for a, b in zip(losses[True], losses[False]):
-        # same kernels underneath, only the loss plumbing differs.  Not bit-equal run to run: split-K weight gradients add
-        # with fp32 atomics, and AdamW's first updates are ~lr * sign(g), so an element whose gradient is ~0 may flip; the
-        # second / third losses were observed to take values 0.2 % apart between identical runs (44.048 / 43.952, 44.569 / 44.540)
-        assert abs(a - b) < 5e-3 * abs(b)
+        # same kernels underneath, only the loss plumbing differs (bf16 dcos from the fused pass vs fp32 dlogits from autograd);
+        # in deterministic mode nothing else separates the two runs
+        assert abs(a - b) < 2e-3 * abs(b)
     for a, b in zip(losses[True], ref):
         assert abs(a - b) < 3e-2 * abs(b)
 

@@ -24,7 +24,7 @@ def t(f, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 fwd = lambda: lib.stem_fwd(x.data_ptr(), w.data_ptr(), z.data_ptr(), sums.data_ptr(), B, H, H, Co, scr.data_ptr(), scr.numel(), s)
-wg = lambda: lib.stem_wgrad(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, H, Co, s)
+wg = lambda: lib.stem_wgrad(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, H, Co, scr.data_ptr(), scr.numel(), s)
 by = x.numel() * 4 + z.numel() * 2
 tf, tw = t(fwd), t(wg)
 print(f"stem fwd {tf:7.1f} us {by/tf/1e3:6.0f} GB/s   wgrad {tw:7.1f} us {by/tw/1e3:6.0f} GB/s")
@@ -37,6 +37,6 @@ print("fwd relerr", ((z.float() - ref).norm() / ref.norm()).item(), " sums reler
 dw.zero_(); wg()
 xr = x[:32]; wr = w.clone().requires_grad_(True)
 dw32 = torch.zeros_like(w)
-lib.stem_wgrad(dz.data_ptr(), xr.data_ptr(), dw32.data_ptr(), 32, H, H, Co, s)
+lib.stem_wgrad(dz.data_ptr(), xr.data_ptr(), dw32.data_ptr(), 32, H, H, Co, scr.data_ptr(), scr.numel(), s)
 F.conv2d(xr, wr, None, stride=2, padding=1).backward(dz[:32 * Ho * Ho].float().view(32, Ho, Ho, Co).permute(0, 3, 1, 2))
 print("wgrad relerr (32 images)", ((dw32 - wr.grad).norm() / wr.grad.norm()).item())
