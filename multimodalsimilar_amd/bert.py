@@ -218,6 +218,25 @@ class BertModel(nn.Module):
             if position_ids.dim() == 1:
                 position_ids = position_ids.unsqueeze(0)
             position_ids = position_ids.to(device=input_ids.device, dtype=torch.long).expand(input_ids.shape).contiguous()
+        # The fused attention kernels hold a whole sequence of 32 / 64 / 128 keys per workgroup.  Other lengths up to 128 (an
+        # inference caller's max_length; the training path pads to 128, multimodal_dataset.py:44-48) run as the next supported
+        # length with the extra positions masked out: masked keys get zero attention weight and only the [CLS] row is pooled,
+        # so the result is that of the unpadded sequence.
+        S = input_ids.shape[1]
+        S_run = 32 if S <= 32 else (64 if S <= 64 else 128)
+        if S > 128:
+            raise ValueError(f"BertModel: sequences longer than 128 tokens are not supported by the fused attention kernels (got {S})")
+        if S_run != S:
+            if S_run > self.config.max_position_embeddings and position_ids is None:
+                raise ValueError("BertModel: position table shorter than the padded sequence")
+            pad = S_run - S
+            F = torch.nn.functional
+            if attention_mask is None:
+                attention_mask = torch.ones_like(input_ids)
+            input_ids = F.pad(input_ids, (0, pad))
+            attention_mask = F.pad(attention_mask, (0, pad))
+            token_type_ids = None if token_type_ids is None else F.pad(token_type_ids, (0, pad))
+            position_ids = None if position_ids is None else F.pad(position_ids, (0, pad))
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if need_grad:
             pooled = _BertFn.apply(self._anchor, self, input_ids, token_type_ids, attention_mask, position_ids)

@@ -32,3 +32,19 @@ def search_inner_product(queries, database, k, normalize=True):
     D[:, :kk] = np.take_along_axis(s, order, 1).astype(np.float32)
     I[:, :kk] = order
     return D, I
+
+
+def search_l2(queries, database, k):
+    """faiss.IndexFlatL2 (multimodal_infer.py:140-145): exact squared Euclidean distances to every stored vector, the k smallest
+    per query in ascending order, -1 / +inf padding; equal distances by ascending index (implementation-defined in faiss)."""
+    q = np.asarray(queries, np.float64)
+    d = np.asarray(database, np.float64)
+    s = (q ** 2).sum(1)[:, None] + (d ** 2).sum(1)[None, :] - 2.0 * q @ d.T
+    nq, n = s.shape
+    D = np.full((nq, k), np.inf, np.float32)
+    I = np.full((nq, k), -1, np.int64)
+    kk = min(k, n)
+    order = np.argsort(s, axis=1, kind="stable")[:, :kk]
+    D[:, :kk] = np.maximum(np.take_along_axis(s, order, 1), 0.0).astype(np.float32)
+    I[:, :kk] = order
+    return D, I

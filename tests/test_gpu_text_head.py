@@ -219,3 +219,80 @@ def test_text_tower_against_oracle_fresh_inputs():
               "encoder.layer.0.intermediate.dense.bias", "embeddings.LayerNorm.weight",
               "embeddings.position_embeddings.weight"):
         assert relerr(named[k].grad, sdr[k].grad) < 6e-2, k
+
+
+def test_hf_bert_model_converts_and_matches_its_own_forward():
+    """NlpClassifier is handed an HF ``BertModel`` in the reference (nlp_classifier_train.py:63-64).  ``as_native`` converts one
+    (weights copied by HF's own key names); the native tower on the GPU must reproduce the HF module's eager CPU forward --
+    pooled output and, through the head, the loss and the embedding-table gradients -- with ragged masks, token types and
+    explicit position ids (nlp_classifier.py:23-27 forwards all of them)."""
+    import transformers
+    from nlp_classifier import NlpClassifier
+    cfg = transformers.BertConfig(vocab_size=211, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=512,
+                                  max_position_embeddings=80, type_vocab_size=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cfg._attn_implementation = "eager"
+    torch.manual_seed(0)
+    hf = transformers.BertModel(cfg).eval()
+    g = torch.Generator().manual_seed(1)
+    B, S = 6, 64
+    ids = torch.randint(0, 211, (B, S), generator=g)
+    tt = torch.randint(0, 2, (B, S), generator=g)
+    mask = (torch.arange(S).unsqueeze(0) < torch.randint(5, S + 1, (B, 1), generator=g)).long()
+    pos = (torch.arange(S).unsqueeze(0) + torch.randint(0, 16, (B, 1), generator=g))          # shifted position ids per row
+    y = torch.randint(0, 50, (B,), generator=g)
+    model = NlpClassifier(hf, num_labels=50)                   # converts: as_native(hf)
+    head_w = model.classifier.weight.detach().clone()
+    for p in hf.parameters():
+        p.requires_grad_(True)
+    out = hf(input_ids=ids, attention_mask=mask, token_type_ids=tt, position_ids=pos).pooler_output
+    from oracle import arcface_ref
+    hw = head_w.clone().requires_grad_(True)
+    ref_loss = arcface_ref.ce_loss(arcface_ref.arcface_forward(out, hw, y, 64.0, 0.40), y)
+    ref_loss.backward()
+    model.to(DEV).train()
+    emb = model.predict_emb(ids.to(DEV), tt.to(DEV), pos.to(DEV), mask.to(DEV))
+    assert relerr(emb, out) < 1e-2
+    loss, _ = model.forward_loss(ids.to(DEV), tt.to(DEV), pos.to(DEV), mask.to(DEV), y.to(DEV))
+    loss.backward()
+    model.ptm.check_indices()
+    assert abs(loss.item() - ref_loss.item()) < 1e-2 * ref_loss.item()
+    named = dict(model.ptm.named_parameters())
+    hfn = dict(hf.named_parameters())
+    for k in ("embeddings.position_embeddings.weight", "embeddings.token_type_embeddings.weight", "embeddings.word_embeddings.weight",
+              "encoder.layer.2.output.dense.weight", "encoder.layer.0.attention.self.query.weight", "pooler.dense.weight"):
+        assert relerr(named[k].grad, hfn[k].grad) < 6e-2, k
+    # position rows that were never indexed keep a zero gradient: the scatter went to the rows the ids name
+    used = torch.zeros(80, dtype=torch.bool)
+    used[pos.flatten()] = True
+    assert float(named["embeddings.position_embeddings.weight"].grad[~used.to(DEV)].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("S", [7, 40, 100, 128])
+def test_sequence_lengths_other_than_the_kernel_sizes(S):
+    """An inference caller with another max_length (the kernels hold 32 / 64 / 128 keys per workgroup): the text tower pads to
+    the next supported length with the extra positions masked; pooled output and gradients equal the oracle's on the
+    UNPADDED sequence."""
+    from oracle import bert_ref
+    from multimodalsimilar_amd.bert import BertModel, BertConfig
+    shape = bert_ref.BertShape(300, 128, 2, 2, 512, 160)
+    sd = bert_ref.init_state(shape, seed=5)
+    ptm = BertModel(BertConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
+                               max_position_embeddings=160, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+    ptm.load_state_dict(sd)
+    ptm.to(DEV).train()
+    g = torch.Generator().manual_seed(S)
+    B = 5
+    ids = torch.randint(0, 300, (B, S), generator=g)
+    mask = (torch.arange(S).unsqueeze(0) < torch.randint(1, S + 1, (B, 1), generator=g)).long()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = bert_ref.bert_forward(sdr, shape, ids, None, mask)
+    w = torch.randn(B, 128, generator=g)
+    (ref * w).sum().backward()
+    out = ptm(input_ids=ids.to(DEV), attention_mask=mask.to(DEV)).pooler_output
+    assert out.shape == (B, 128) and relerr(out, ref) < 1e-2
+    (out * w.to(DEV)).sum().backward()
+    named = dict(ptm.named_parameters())
+    for k in ("encoder.layer.0.attention.self.value.weight", "encoder.layer.1.intermediate.dense.weight", "embeddings.word_embeddings.weight"):
+        assert relerr(named[k].grad, sdr[k].grad) < 6e-2, k
+    with pytest.raises(ValueError):
+        ptm(input_ids=torch.zeros(1, 129, dtype=torch.long, device=DEV))
