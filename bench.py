@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--ragged-masks", action="store_true", help="per-row sequence lengths ~ U{8..S} (SURVEY 8d realism run; not the headline)")
     ap.add_argument("--literal-loss", action="store_true", help="materialised logits + nn.CrossEntropyLoss instead of the fused head")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python (eager) instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
     # before the first HIP call of the process: the host driver only supports dmabuf IPC (RCCL / cross-process tensors)
@@ -203,16 +204,31 @@ def main():
         torch.cuda.synchronize()
         torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=int(os.environ["MMSIM_MAIN_PRIORITY"])))
 
+    # The step is ~2 500 launches; issued from Python they cost as much host time as the step takes on the GPU.  Single-process
+    # runs therefore replay the step as ONE captured hipGraph (train.GraphedTrainStep: same kernels, same order, same streams;
+    # step-dependent scalars read from device memory).  Data-parallel runs keep the eager step (collectives are not captured).
+    gstep, launch = None, "eager (one Python launch per kernel)"
+    if world == 1 and not args.no_graph and os.environ.get("MMSIM_GRAPH", "1") != "0" and not args.literal_loss:
+        try:
+            gstep = train.GraphedTrainStep(step, batch, warmup=2)
+            launch = "hipGraph replay (the whole step captured once: forward, loss, backward, both AdamW updates)"
+        except Exception as e:      # never lose the measurement to a capture problem: fall back to the eager step, and say so
+            print(f"bench: hipGraph capture failed ({type(e).__name__}: {e}); running the eager step", file=sys.stderr, flush=True)
+            step.opt_emb.dev_hyper = step.opt_fc.dev_hyper = None
+            ops.lib.set_step_seed_ptr(None)
+            gstep = None
+    run = gstep.step if gstep is not None else step.step
+
     for _ in range(args.warmup):
-        loss, _ = step.step(batch)
+        loss, _ = run(batch)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.on = True
+    timer.on = gstep is None
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, pred = step.step(batch)
+        loss, pred = run(batch)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -225,6 +241,20 @@ def main():
         elapsed = float(t.item())
     model.classifier.check_labels()
     lossv = float(loss.item())
+
+    # roofline of the dominant kernel: HIP events around each of its launches.  Events cannot bracket a launch inside a replayed
+    # graph, so with the graph path they are taken over the same number of EAGER steps right after the timed region (the graph
+    # replays exactly these kernels; the rocprofv3 summary under profiles/ is of the replayed graph itself).
+    roof_from = "the timed region"
+    if gstep is not None:
+        gstep.close()
+        step.step(batch)
+        timer.on = True
+        for _ in range(min(args.steps, 5)):
+            step.step(batch)
+        torch.cuda.synchronize()
+        timer.on = False
+        roof_from = f"{min(args.steps, 5)} eager steps right after the timed region (same kernels as the replayed graph)"
 
     # The towers overlap on two HIP streams inside the timed region, so the dominant kernel's launches above share the CUs
     # with image-tower kernels.  Its rate with the chip to itself is measured right after, outside the timed region
@@ -265,7 +295,7 @@ def main():
                        "dropout": not args.no_dropout, "attention_mask": "ragged U{8..S}" if args.ragged_masks else "all ones", "loss_path": "literal" if args.literal_loss else "fused",
                        "algorithmic_gflop_per_pair": fpp / 1e9,
                        "step_mfma_frac": (fpp * cfg["batch"] / (ms * 1e-3) / 1e12) / MFMA_BF16_PEAK_TFLOPS,
-                       "final_loss": lossv,
+                       "final_loss": lossv, "launch": launch,
                        # every MMSIM_* switch set in this process (they select schedules / kernels): empty = the defaults
                        "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MMSIM_")}},
             "roofline": None if g is None else {
@@ -273,7 +303,7 @@ def main():
                 "achieved": g["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": _pmc_traffic(args.config)[0], "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_gemm_pp64.json)",
                 "algorithmic_bytes_per_launch": _pmc_traffic(args.config)[1],
-                "launches": g["launches"], "avg_launch_us": g["avg_us"],
+                "launches": g["launches"], "avg_launch_us": g["avg_us"], "measured_over": roof_from,
                 "concurrent_with": "image-tower kernels on a second stream" if g_excl else None,
                 "achieved_exclusive": g_excl["tflops"] if g_excl else None,
                 "frac_exclusive": g_excl["tflops"] / MFMA_BF16_PEAK_TFLOPS if g_excl else None},

@@ -27,6 +27,10 @@ const char* mmsim_last_error(void);
 /* Deterministic (verification) mode, process-wide: every cross-workgroup sum in a fixed order (partial slabs reduced by one
  * workgroup per output, no split-K, single-slice pooling, serial embedding scatter).  Results are then bit-identical from run
  * to run; the default mode keeps the faster forms whose fp32 atomic adds arrive in varying order.  Costs step time. */
+/* hipGraph replay of a training step: dropout seeds are kernel arguments, which a captured graph freezes.  With a device word
+ * registered here every dropout kernel (embeddings, hidden / attention dropout of modeling_bert.py:68-108,111-136,289-293, the
+ * Dropout(0.5) of cv_classifier.py:52) adds *dev_ptr to its seed argument at run time.  NULL (default) = seeds are the arguments. */
+int mmsim_set_step_seed_ptr(const unsigned long long* dev_ptr);
 int mmsim_set_deterministic(int on);
 int mmsim_get_deterministic(void);
 
@@ -283,17 +287,18 @@ int mmsim_broadcast_pool_grad(const float* dpool, void* dy, int B, int HW, int C
 
 /* ---- torch.optim.AdamW.step() (multimodal_classifier_train.py:152-156,161,195,199) over a flat fp32 buffer.
  * g is multiplied by grad_scale first (1/world_size after an all-reduce sum); bf16_shadow (may be NULL)
- * receives the updated parameters rounded to bf16 for the next forward.  n % 4 == 0.  step is 1-based. */
+ * receives the updated parameters rounded to bf16 for the next forward.  n % 4 == 0.  step is 1-based.  * dev_hyper (both AdamW entry points; NULL = use the arguments): device float[3] = {lr, 1 - beta1^step, 1 / sqrt(1 - beta2^step)}
+ * read by the kernel at run time instead of lr / step -- the step-dependent scalars of a launch captured in a hipGraph. */
 int mmsim_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, unsigned long long n, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                     void* stream);
+                     const float* dev_hyper, void* stream);
 
 /* The same update for a row-normalised weight matrix p [R][D] (the ArcFace head), one wave per row, which also leaves
  * w_hat bf16 [R][D] = p / max(||p_row||, l2_eps) and inv_norm [R] for the NEXT forward: F.normalize(self.weight) (arcface.py:47)
  * then needs no pass of its own.  D % 4 == 0, D <= 4096. */
 int mmsim_adamw_rows_l2norm(float* p, const float* g, float* m, float* v, void* w_hat, float* inv_norm, int R, int D,
                             float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                            float l2_eps, void* stream);
+                            float l2_eps, const float* dev_hyper, void* stream);
 
 /* ---- exhaustive inner-product top-k search (nlp_infer.py:139-152, daodian_infer.py:225-230, 295-302:
  * faiss.normalize_L2 + IndexFlat(METRIC_INNER_PRODUCT).add / .search) ------------------------------------------------

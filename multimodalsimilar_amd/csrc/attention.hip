@@ -26,7 +26,7 @@ struct AttnParams {
   float* dbias_parts;    // backward: per-batch-element column sums of dqkv, slab [B][3H] (NULL = off)
   int ld_qkv, ld_ctx, heads, H;
   float scale;
-  unsigned long long seed; unsigned int stream, thresh; float inv_keep;
+  unsigned long long seed; const unsigned long long* seed_dev; unsigned int stream, thresh; float inv_keep;
 };
 
 __device__ __forceinline__ bf8 cvt8(const f16v& a, int s2, float mul) {
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_FW
   const float inv = 1.0f / sum;
   if (hh == 0 && p.lse) p.lse[(size_t)bh * S + qrow] = mx + __logf(sum);
   if (p.thresh) {                       // accumulator registers r, r+1 (r even) are keys k, k+1: one hash per pair
-    const uint32_t dkey = drop_key(p.seed, p.stream);
+    const uint32_t dkey = drop_key(step_seed(p.seed, p.seed_dev), p.stream);
     const unsigned long long rowbase = ((unsigned long long)bh * S + qrow) * S;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
   park(0);
   __syncthreads();
   const float mbk = mb[key];
-  const uint32_t dkey = drop_key(p.seed, p.stream);
+  const uint32_t dkey = drop_key(step_seed(p.seed, p.seed_dev), p.stream);
 
   f16v dV[2], dK[2];
 #pragma unroll
@@ -406,7 +406,7 @@ extern "C" int mmsim_attn_fwd(const void* qkv, int ld_qkv, const long long* mask
   p.qkv = (const bf16*)qkv; p.mask = (const int64_t*)mask; p.ctx = (bf16*)ctx; p.dctx = nullptr; p.lse = lse; p.dqkv = nullptr;
   p.dbias_parts = nullptr;
   p.ld_qkv = ld_qkv; p.ld_ctx = ld_ctx; p.heads = heads; p.H = H; p.scale = 0.125f;
-  p.seed = seed; p.stream = stream_id;
+  p.seed = seed; p.seed_dev = mmsim_step_seed_ptr(); p.stream = stream_id;
   p.thresh = dropout_p > 0.f ? (unsigned int)((double)dropout_p * 4294967296.0) : 0u;
   p.inv_keep = 1.0f / (1.0f - dropout_p);
   const int NT = S / 32;
@@ -433,7 +433,7 @@ static int attn_bwd_impl(const void* qkv, int ld_qkv, const long long* mask, con
   p.qkv = (const bf16*)qkv; p.mask = (const int64_t*)mask; p.ctx = (bf16*)ctx; p.dctx = (const bf16*)dctx;
   p.lse = (float*)lse; p.dqkv = (bf16*)dqkv; p.dbias_parts = dbias_parts;
   p.ld_qkv = ld_qkv; p.ld_ctx = ld_ctx; p.heads = heads; p.H = H; p.scale = 0.125f;
-  p.seed = seed; p.stream = stream_id;
+  p.seed = seed; p.seed_dev = mmsim_step_seed_ptr(); p.stream = stream_id;
   p.thresh = dropout_p > 0.f ? (unsigned int)((double)dropout_p * 4294967296.0) : 0u;
   p.inv_keep = 1.0f / (1.0f - dropout_p);
   const int NT = S / 32;

@@ -20,6 +20,7 @@ typedef __attribute__((ext_vector_type(8))) short s8;
 extern "C" void mmsim_set_error(const char* msg);
 int mmsim_check_launch(const char* what);
 int mmsim_current_device(void);
+const unsigned long long* mmsim_step_seed_ptr(void);      // core.hip: device word added to every dropout seed (graph replay), or NULL
 int mmsim_deterministic(void);      // core.hip: fixed-order reductions everywhere (verification mode)
 
 #define MMSIM_REQUIRE(cond, msg)                 \
@@ -85,6 +86,7 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
+__device__ __forceinline__ uint64_t step_seed(uint64_t seed, const unsigned long long* dev) { return dev ? seed + *dev : seed; }
 __device__ __forceinline__ uint32_t drop_key(uint64_t seed, uint32_t stream) {
   return hash32((uint32_t)seed ^ hash32(stream * 0x85EBCA6BU + (uint32_t)(seed >> 32) * 0x9E3779B9U + 0x632BE5ABU));
 }

@@ -1098,19 +1098,19 @@ __global__ void bn1d_bwd_kernel(const float* dy, const float* x, const float* me
 
 // elementwise helpers for the tower top
 __global__ void dropout_cast_kernel(const float* x, bf16* y, size_t n, unsigned long long seed, unsigned int stream, unsigned int thresh,
-                                    float inv_keep) {
+                                    float inv_keep, const unsigned long long* seed_dev) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float v = x[i];
-  if (thresh) v = drop_keep(seed, stream, i, thresh) ? v * inv_keep : 0.f;
+  if (thresh) v = drop_keep(step_seed(seed, seed_dev), stream, i, thresh) ? v * inv_keep : 0.f;
   y[i] = f2bf(v);
 }
 __global__ void dropout_bwd_kernel(const float* dy, float* dx, size_t n, unsigned long long seed, unsigned int stream, unsigned int thresh,
-                                   float inv_keep) {
+                                   float inv_keep, const unsigned long long* seed_dev) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float v = dy[i];
-  if (thresh) v = drop_keep(seed, stream, i, thresh) ? v * inv_keep : 0.f;
+  if (thresh) v = drop_keep(step_seed(seed, seed_dev), stream, i, thresh) ? v * inv_keep : 0.f;
   dx[i] = v;
 }
 // global-average-pool backward fused with the head BN+SiLU backward input: dy[b,hw,c] = dpool[b,c] / HW   (bf16)
@@ -1416,7 +1416,7 @@ extern "C" int mmsim_dropout_cast(const float* x, void* y_bf16, unsigned long lo
   MMSIM_REQUIRE(x && y_bf16 && p >= 0.f && p < 1.f, "dropout_cast: bad arguments");
   if (n == 0) return MMSIM_OK;
   hipLaunchKernelGGL(dropout_cast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)y_bf16,
-                     (size_t)n, seed, stream_id, p > 0.f ? (unsigned int)((double)p * 4294967296.0) : 0u, 1.0f / (1.0f - p));
+                     (size_t)n, seed, stream_id, p > 0.f ? (unsigned int)((double)p * 4294967296.0) : 0u, 1.0f / (1.0f - p), mmsim_step_seed_ptr());
   return mmsim_check_launch("dropout_cast");
 }
 extern "C" int mmsim_dropout_bwd(const float* dy, float* dx, unsigned long long n, float p, unsigned long long seed,
@@ -1424,7 +1424,7 @@ extern "C" int mmsim_dropout_bwd(const float* dy, float* dx, unsigned long long 
   MMSIM_REQUIRE(dy && dx && p >= 0.f && p < 1.f, "dropout_bwd: bad arguments");
   if (n == 0) return MMSIM_OK;
   hipLaunchKernelGGL(dropout_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, (size_t)n, seed,
-                     stream_id, p > 0.f ? (unsigned int)((double)p * 4294967296.0) : 0u, 1.0f / (1.0f - p));
+                     stream_id, p > 0.f ? (unsigned int)((double)p * 4294967296.0) : 0u, 1.0f / (1.0f - p), mmsim_step_seed_ptr());
   return mmsim_check_launch("dropout_bwd");
 }
 extern "C" int mmsim_broadcast_pool_grad(const float* dpool, void* dy, int B, int HW, int C, void* stream) {

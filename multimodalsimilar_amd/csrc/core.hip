@@ -39,6 +39,13 @@ extern "C" int mmsim_set_deterministic(int on) { g_deterministic = on ? 1 : 0; r
 extern "C" int mmsim_get_deterministic(void) { return g_deterministic; }
 int mmsim_deterministic(void) { return g_deterministic; }
 
+// Step-seed word for hipGraph replay.  Dropout seeds are kernel ARGUMENTS, which a captured graph freezes; when this pointer is
+// set, every dropout kernel adds *ptr (read on the device at run time) to its seed argument, so a replayed step draws new masks
+// after the host has bumped the word (multimodalsimilar_amd.train.GraphedTrainStep).  NULL (default): seeds are the arguments.
+static const unsigned long long* g_step_seed_ptr = nullptr;
+extern "C" int mmsim_set_step_seed_ptr(const unsigned long long* dev_ptr) { g_step_seed_ptr = dev_ptr; return MMSIM_OK; }
+const unsigned long long* mmsim_step_seed_ptr(void) { return g_step_seed_ptr; }
+
 extern "C" int mmsim_version(void) { return 200; }
 
 // Returns the number of visible HIP devices, or -1 with the error string set.

@@ -245,7 +245,8 @@ __global__ void tanh_bwd_kernel(const float* dpooled, const float* pooled, bf16*
 // p <- p(1 - lr wd); m <- b1 m + (1-b1) g; v <- b2 v + (1-b2) g^2; p <- p - (lr/bc1) m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16* shadow, size_t n,
                                                     float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                    float rsqrt_bc2, float gscale) {
+                                                    float rsqrt_bc2, float gscale, const float* hyper) {
+  if (hyper) { lr = hyper[0]; bc1 = hyper[1]; rsqrt_bc2 = hyper[2]; }      // step-dependent scalars from device memory (graph replay)
   size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   const size_t stride = (size_t)gridDim.x * 1024;
   for (; i < n; i += stride) {   // n is padded to a multiple of 4 by the host
@@ -282,7 +283,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
 template <int MAXC>
 __global__ __launch_bounds__(256) void adamw_rows_l2norm_kernel(float* p, const float* g, float* m, float* v, bf16* wh, float* inv_norm,
                                                                 int R, int D, float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                                float rsqrt_bc2, float gscale, float l2eps) {
+                                                                float rsqrt_bc2, float gscale, float l2eps, const float* hyper) {
+  if (hyper) { lr = hyper[0]; bc1 = hyper[1]; rsqrt_bc2 = hyper[2]; }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wv;
   if (row >= R) return;
@@ -422,7 +424,7 @@ extern "C" int mmsim_arcface_rowfix(const void* dcos, const float* cosm, int ld,
 
 extern "C" int mmsim_adamw_rows_l2norm(float* p, const float* g, float* m, float* v, void* w_hat, float* inv_norm, int R, int D,
                                        float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                                       float l2_eps, void* stream) {
+                                       float l2_eps, const float* dev_hyper, void* stream) {
   MMSIM_REQUIRE(p && g && m && v && w_hat && inv_norm && R > 0 && D > 0, "adamw_rows_l2norm: null operand");
   MMSIM_REQUIRE(D % 4 == 0 && D <= 4096, "adamw_rows_l2norm: D must be a multiple of 4 and <= 4096");
   MMSIM_REQUIRE(step >= 1, "adamw: step is 1-based");
@@ -430,7 +432,7 @@ extern "C" int mmsim_adamw_rows_l2norm(float* p, const float* g, float* m, float
   const dim3 grid((R + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define ARL(MC) hipLaunchKernelGGL((adamw_rows_l2norm_kernel<MC>), grid, block, 0, s, p, g, m, v, (bf16*)w_hat, inv_norm, R, D, lr, beta1, \
-                                   beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, l2_eps)
+                                   beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, l2_eps, dev_hyper)
   if (D <= 1024) ARL(4); else if (D <= 2048) ARL(8); else if (D <= 3072) ARL(12); else ARL(16);
 #undef ARL
   return mmsim_check_launch("adamw_rows_l2norm");
@@ -474,13 +476,13 @@ extern "C" int mmsim_tanh_bwd(const float* dpooled, const float* pooled, void* d
 
 extern "C" int mmsim_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, unsigned long long n,
                                 float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                                float grad_scale, void* stream) {
+                                float grad_scale, const float* dev_hyper, void* stream) {
   MMSIM_REQUIRE(p && g && m && v, "adamw: null operand");
   MMSIM_REQUIRE(n % 4 == 0, "adamw: flat buffer length must be a multiple of 4");
   MMSIM_REQUIRE(step >= 1, "adamw: step is 1-based");
   if (n == 0) return MMSIM_OK;
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)bf16_shadow,
-                     (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+                     (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, dev_hyper);
   return mmsim_check_launch("adamw");
 }

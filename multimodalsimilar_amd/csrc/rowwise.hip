@@ -20,16 +20,16 @@ __device__ __forceinline__ void st4(bf16* p, float4 v) {
   *reinterpret_cast<bf4*>(p) = o;
 }
 
-struct Drop { unsigned long long seed; unsigned int stream, thresh; float inv_keep; };
+struct Drop { unsigned long long seed; const unsigned long long* seed_dev; unsigned int stream, thresh; float inv_keep; };
 static Drop make_drop(float p, unsigned long long seed, unsigned int stream) {
-  Drop d; d.seed = seed; d.stream = stream;
+  Drop d; d.seed = seed; d.seed_dev = mmsim_step_seed_ptr(); d.stream = stream;
   d.thresh = p > 0.f ? (unsigned int)((double)p * 4294967296.0) : 0u;
   d.inv_keep = 1.0f / (1.0f - p);
   return d;
 }
 __device__ __forceinline__ float4 drop4(float4 v, const Drop& d, unsigned long long idx) {     // idx: a multiple of 4
   if (!d.thresh) return v;
-  const uint32_t key = drop_key(d.seed, d.stream);
+  const uint32_t key = drop_key(step_seed(d.seed, d.seed_dev), d.stream);
   const uint32_t h0 = drop_bits(key, idx >> 1), h1 = drop_bits(key, (idx >> 1) + 1);
   v.x = drop_keep16(h0, 0, d.thresh) ? v.x * d.inv_keep : 0.f;
   v.y = drop_keep16(h0, 1, d.thresh) ? v.y * d.inv_keep : 0.f;

@@ -320,7 +320,7 @@ def cast_to_f32(x, y):
     lib.cast_bf16_to_f32(_p(x), _p(y), x.numel(), _stream())
 
 
-def adamw_step(p, g, m, v, shadow, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+def adamw_step(p, g, m, v, shadow, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, dev_hyper=None):
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, F32, "adamw." + n, 1)
         if t.numel() != p.numel():
@@ -328,10 +328,11 @@ def adamw_step(p, g, m, v, shadow, lr, beta1, beta2, eps, weight_decay, step, gr
     if shadow is not None:
         _chk(shadow, BF16, "adamw.shadow", 1)
     lib.adamw_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
-                   float(weight_decay), int(step), float(grad_scale), _stream())
+                   float(weight_decay), int(step), float(grad_scale), _p(dev_hyper), _stream())
 
 
-def adamw_rows_l2norm(p2d, g2d, m2d, v2d, w_hat, inv_norm, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, l2_eps=1e-12):
+def adamw_rows_l2norm(p2d, g2d, m2d, v2d, w_hat, inv_norm, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, l2_eps=1e-12,
+                      dev_hyper=None):
     """AdamW on a [R, D] weight matrix that also leaves F.normalize(weight) (bf16) and 1/||row|| for the next forward."""
     R, D = p2d.shape
     for t, n in ((p2d, "p"), (g2d, "g"), (m2d, "m"), (v2d, "v")):
@@ -342,7 +343,7 @@ def adamw_rows_l2norm(p2d, g2d, m2d, v2d, w_hat, inv_norm, lr, beta1, beta2, eps
     if tuple(w_hat.shape) != (R, D) or not w_hat.is_contiguous() or inv_norm.numel() != R:
         raise ValueError("adamw_rows: w_hat [R, D] contiguous and inv_norm [R] required")
     lib.adamw_rows_l2norm(_p(p2d), _p(g2d), _p(m2d), _p(v2d), _p(w_hat), _p(inv_norm), R, D, float(lr), float(beta1), float(beta2),
-                          float(eps), float(weight_decay), int(step), float(grad_scale), float(l2_eps), _stream())
+                          float(eps), float(weight_decay), int(step), float(grad_scale), float(l2_eps), _p(dev_hyper), _stream())
 
 
 if os.environ.get("MMSIM_DETERMINISTIC", "0") == "1":

@@ -62,6 +62,9 @@ class FusedAdamW(torch.optim.Optimizer):
         self.grad_scale = grad_scale
         self._t = 0
         self._mv = {}
+        # device float[3] {lr, 1 - beta1^t, 1 / sqrt(1 - beta2^t)} read by the kernels instead of the host values when set: the
+        # step-dependent scalars of an update captured in a hipGraph (train.GraphedTrainStep writes it before every replay)
+        self.dev_hyper = None
 
     def zero_grad(self, set_to_none=False):
         for f in self.flats:
@@ -89,11 +92,11 @@ class FusedAdamW(torch.optim.Optimizer):
                 n = R * D
                 ops.adamw_rows_l2norm(f.master[:n].view(R, D), f.grad[:n].view(R, D), mv[0][:n].view(R, D), mv[1][:n].view(R, D),
                                       w_hat, inv_norm, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._t,
-                                      self.grad_scale)
+                                      self.grad_scale, dev_hyper=self.dev_hyper)
                 rn.mark_normalised()
                 continue
             ops.adamw_step(f.master, f.grad, mv[0], mv[1], f.shadow, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                           g["weight_decay"], self._t, self.grad_scale)
+                           g["weight_decay"], self._t, self.grad_scale, dev_hyper=self.dev_hyper)
             f._shadow_version = f.master._version
             if rn is not None:
                 rn.invalidate_normalised()          # the master changed under the module: its cached w_hat is stale
@@ -125,6 +128,18 @@ class FusedAdamW(torch.optim.Optimizer):
             if mv[0].numel() != f.master.numel():
                 raise ValueError("FusedAdamW.load_state_dict: moment buffer size does not match the flat parameter buffer")
             self._mv[id(f)] = tuple(t.to(device=f.master.device, dtype=torch.float32).clone() for t in mv)
+
+
+def hyper_values(opt, t):
+    """{lr, 1 - beta1^t, 1 / sqrt(1 - beta2^t)} of step t (1-based) for ``opt``'s current learning rate -- computed exactly as
+    mmsim_adamw_step computes them from its arguments (betas as the float32 values the C ABI receives, powers and the square root
+    in double, the results rounded to float32), so that an update fed from device memory is bit-identical to one fed by value."""
+    import math
+    import struct
+    f32 = lambda x: struct.unpack("f", struct.pack("f", x))[0]
+    g = opt.param_groups[0]
+    b1, b2 = f32(g["betas"][0]), f32(g["betas"][1])
+    return [f32(g["lr"]), f32(1.0 - math.pow(b1, t)), f32(1.0 / math.sqrt(1.0 - math.pow(b2, t)))]
 
 
 class FusedAdam(FusedAdamW):

@@ -160,8 +160,8 @@ class TrainStep:
         self.opt_emb.param_groups[0]["lr"] = linear_schedule_lr(self.lr_emb0, self.t, 0, self.total)
         self.opt_fc.param_groups[0]["lr"] = linear_schedule_lr(self.lr_fc0, self.t, self.warmup_fc, self.total)
 
-    def step(self, batch):
-        """One training step; returns (loss tensor, argmax predictions) still on the device (no host sync)."""
+    def _body(self, batch):
+        """The device work of one step: forward, loss, backward, gradient exchange, both optimiser updates (reference order)."""
         model = self.model
         model.train()
         kw = model_inputs(self.kind, batch)
@@ -180,9 +180,117 @@ class TrainStep:
         self.opt_emb.zero_grad()
         self.opt_fc.step()
         self.opt_fc.zero_grad()
+        return loss.detach(), pred
+
+    def _advance(self):
         self.t += 1
         self._set_lr()                          # lr_scheduler_emb.step(); lr_scheduler_fc.step()
-        return loss.detach(), pred
+
+    def step(self, batch):
+        """One training step; returns (loss tensor, argmax predictions) still on the device (no host sync)."""
+        out = self._body(batch)
+        self._advance()
+        return out
+
+
+class GraphedTrainStep:
+    """The training step as ONE hipGraph: captured once, replayed every step.
+
+    Why: a step is ~2 500 kernel launches issued from Python at ~40 us each -- ~105 ms of host time, as long as the step itself.
+    The image tower's backward (~700 short launches) could not even START until the host had finished enqueueing the text
+    tower's (~30 ms), and then ran at the host's launch rate, not the GPU's (rocprofv3 timeline: the image stream idle for 30 ms,
+    then 15 ms of exposed tail).  Replaying a captured graph costs the host ~nothing, so the two towers' streams really overlap.
+
+    What a captured graph freezes, and how each is kept live:
+      * kernel ARGUMENTS that change per step -- the AdamW learning rates / bias corrections and the dropout seeds: the kernels
+        read them from device memory instead (FusedAdamW.dev_hyper, mmsim_set_step_seed_ptr), which this class refreshes with
+        two small host-to-device copies before every replay;
+      * tensor addresses: activations come from the graph's private memory pool (stable across replays), the batch is copied
+        into static input tensors;
+      * host-side decisions (which kernel, which split-K, the margin): fixed per shape -- ``update_m`` or a new batch shape need a
+        new capture (``recapture()``).
+    Single-process only (collectives are left to the eager step).  Semantics are TrainStep.step's, checked against it step by
+    step in tests/test_gpu_graph_step.py."""
+
+    def __init__(self, ts, batch, warmup=2):
+        from .optim import hyper_values
+        from ._lib import lib
+        if ts.exchange is not None:
+            raise ValueError("GraphedTrainStep: data-parallel runs use the eager TrainStep")
+        self.ts, self._hv, self._lib = ts, hyper_values, lib
+        dev = batch["labels"].device
+        self.static = {k: v.clone() for k, v in batch.items()}
+        self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)         # [0:3] towers, [4:7] head (16-byte aligned halves)
+        self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._init_host_ring()
+        self.replays = 0
+        ts.opt_emb.dev_hyper, ts.opt_fc.dev_hyper = self.hyper[0:3], self.hyper[4:7]
+        lib.set_step_seed_ptr(self.seed.data_ptr())
+        self.graph = None
+        self._capture(warmup)
+
+    RING = 64
+
+    def _init_host_ring(self):
+        # The host runs AHEAD of the device (that is the point of replaying a graph): a single pinned staging buffer would be
+        # overwritten with step k+1's values before step k's asynchronous copy has read it.  A ring of pinned rows, each guarded
+        # by the event recorded behind the copies that read it.
+        self._h_hyper = torch.zeros(self.RING, 8, dtype=torch.float32).pin_memory()
+        self._h_seed = torch.zeros(self.RING, 1, dtype=torch.int64).pin_memory()
+        self._h_done = [None] * self.RING
+
+    def _prepare(self):
+        """Write the NEXT step's scalars (lr and bias corrections of both optimisers, the dropout step word) to the device."""
+        ts = self.ts
+        slot = self.replays % self.RING
+        if self._h_done[slot] is not None:
+            self._h_done[slot].synchronize()             # the copies that read this row 64 steps ago have run
+        self._h_hyper[slot, 0:3] = torch.tensor(self._hv(ts.opt_emb, ts.opt_emb._t + 1))
+        self._h_hyper[slot, 4:7] = torch.tensor(self._hv(ts.opt_fc, ts.opt_fc._t + 1))
+        self._h_seed[slot, 0] = (self.replays * 0x9E3779B97F4A7C15 + 0x5851F42D4C957F2D) & 0x7FFFFFFFFFFFFFFF
+        self.hyper.copy_(self._h_hyper[slot], non_blocking=True)
+        self.seed.copy_(self._h_seed[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._h_done[slot] = ev
+        self.replays += 1
+
+    def _capture(self, warmup):
+        ts = self.ts
+        side = torch.cuda.Stream()                       # torch: warm up on a side stream before capturing
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                      # real (eager) steps: lazy initialisation, scratch buffers, autotuned choices
+                self._prepare()
+                ts._body(self.static)
+                ts._advance()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        t_emb, t_fc = ts.opt_emb._t, ts.opt_fc._t
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.pred = ts._body(self.static)
+        ts.opt_emb._t, ts.opt_fc._t = t_emb, t_fc        # capture records, it does not run: undo the host-side step counters
+
+    def recapture(self, warmup=0):
+        self.graph = None
+        self._capture(warmup)
+
+    def step(self, batch):
+        for k, v in batch.items():
+            if v is not self.static[k]:
+                self.static[k].copy_(v, non_blocking=True)
+        self._prepare()
+        self.graph.replay()
+        ts = self.ts
+        ts.opt_emb._t += 1
+        ts.opt_fc._t += 1
+        ts._advance()
+        return self.loss, self.pred
+
+    def close(self):
+        self._lib.set_step_seed_ptr(None)
+        self.ts.opt_emb.dev_hyper = self.ts.opt_fc.dev_hyper = None
 
 
 class CvTrainLoop:
