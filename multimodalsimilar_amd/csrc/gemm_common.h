@@ -196,9 +196,87 @@ __device__ __forceinline__ void stats_epilogue(const GemmParams& p, f4 (&acc)[4]
   }
 }
 
+// bf16-output epilogue for FULL tiles with 16-byte accesses (cdna_hip_programming.md T21): a lane owns 8 consecutive columns, so
+// a 128-byte row segment of the wave's 64 x 64 sub-tile is 8 lanes x dwordx4 instead of 16 lanes x dwordx2 -- half the store
+// (and aux load) instructions.  The epilogue of the 256 x 256 tiles is store-ISSUE-bound (~7 B/cycle/CU with every wave storing
+// dwordx2: ~15 us per tile for the two-output GELU epilogue against ~23 us of main loop at K = 1024).
+template <int EPI>
+__device__ __forceinline__ void fast_epilogue_bf16_wide(const GemmParams& p, f4 (&acc)[4][4], int row0, int col0, int lane, bool first_split,
+                                                        float* tile) {
+  const int c8 = (lane & 7) * 8, n = col0 + c8, rsub = lane >> 3;
+  constexpr bool RD = (EPI == EPI_MUL_GELU_GRAD || EPI == EPI_ADD || EPI == EPI_MUL);
+  bf8 auxv[8];
+  if (RD) {          // all eight row segments of the lane requested ahead of the staging round trip
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const size_t m = (size_t)(row0 + it * 8 + rsub);
+      if (EPI == EPI_ADD) auxv[it] = *reinterpret_cast<const bf8*>(p.aux_in + m * p.ld_aux + n);
+      else auxv[it] = __builtin_nontemporal_load(reinterpret_cast<const bf8*>(p.aux_in + m * p.ld_aux + n));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f4*>(tile + (i * 16 + (lane & 15)) * EP_PITCH + j * 16 + (lane >> 4) * 4) = acc[i][j];
+  float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (p.bias != nullptr && first_split) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+    bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+  }
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = it * 8 + rsub;
+    const size_t m = (size_t)(row0 + r);
+    const f4 a0 = *reinterpret_cast<const f4*>(tile + r * EP_PITCH + c8), a1 = *reinterpret_cast<const f4*>(tile + r * EP_PITCH + c8 + 4);
+    float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
+    if (EPI == EPI_GELU_DGELU) {
+      bf8 dg;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { float g, d; gelu_both_f(bf2f(f2bf(v[e])), g, d); v[e] = g; dg[e] = f2bf(d); }
+      __builtin_nontemporal_store(dg, reinterpret_cast<bf8*>(p.aux_out + m * p.ld_aux + n));
+    } else if (EPI == EPI_GELU) {
+      bf8 pre;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { pre[e] = f2bf(v[e]); v[e] = gelu_f(bf2f(pre[e])); }
+      __builtin_nontemporal_store(pre, reinterpret_cast<bf8*>(p.aux_out + m * p.ld_aux + n));
+    } else if (EPI == EPI_MUL) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= bf2f(auxv[it][e]);
+    } else if (EPI == EPI_MUL_GELU_GRAD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(bf2f(auxv[it][e]));
+    } else if (EPI == EPI_ADD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bf2f(auxv[it][e]);
+    } else if (EPI == EPI_TANH) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+    }
+    bf8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+    __builtin_nontemporal_store(o, reinterpret_cast<bf8*>(reinterpret_cast<bf16*>(p.C) + m * p.ldc + n));
+  }
+}
+
 template <int CMODE, bool CHECK = false>
 __device__ __forceinline__ void fast_epilogue_epi(const GemmParams& p, f4 (&acc)[4][4], int row0, int col0, int lane, bool first_split,
                                                   float* tile) {
+  if (CMODE == 0 && !CHECK && (p.ldc % 8) == 0 && (p.ld_aux % 8) == 0) {      // launch-uniform: bf16 output, full tiles, 16-byte rows
+    switch (p.epi) {
+      case EPI_GELU: fast_epilogue_bf16_wide<EPI_GELU>(p, acc, row0, col0, lane, first_split, tile); break;
+      case EPI_MUL_GELU_GRAD: fast_epilogue_bf16_wide<EPI_MUL_GELU_GRAD>(p, acc, row0, col0, lane, first_split, tile); break;
+      case EPI_ADD: fast_epilogue_bf16_wide<EPI_ADD>(p, acc, row0, col0, lane, first_split, tile); break;
+      case EPI_TANH: fast_epilogue_bf16_wide<EPI_TANH>(p, acc, row0, col0, lane, first_split, tile); break;
+      case EPI_GELU_DGELU: fast_epilogue_bf16_wide<EPI_GELU_DGELU>(p, acc, row0, col0, lane, first_split, tile); break;
+      case EPI_MUL: fast_epilogue_bf16_wide<EPI_MUL>(p, acc, row0, col0, lane, first_split, tile); break;
+      default: fast_epilogue_bf16_wide<EPI_NONE>(p, acc, row0, col0, lane, first_split, tile); break;
+    }
+    return;
+  }
   switch (p.epi) {
     case EPI_GELU: fast_epilogue<EPI_GELU, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile); break;
     case EPI_MUL_GELU_GRAD: fast_epilogue<EPI_MUL_GELU_GRAD, CMODE, CHECK>(p, acc, row0, col0, lane, first_split, tile); break;
