@@ -72,8 +72,26 @@ __device__ __forceinline__ void store_tile(char* lds, int tid, const uint4 (&reg
 
 // BN-affine + SiLU (+ SE gate) applied to a staged tile in registers.  The "pixel" index is the row of a
 // k-major operand / the k index of a transposed one; the channel index is the other one.
+// The per-(image, channel) gate values are REQUESTED with the tile's own loads (xform_request, ahead of the current step's
+// MFMAs) and applied after them (xform_tile): requested at the point of use they cost every K-step an exposed L2 round trip.
+struct XfGate { float4 g0[4], g1[4]; };
 template <bool TRANS>
-__device__ __forceinline__ void xform_tile(const GemmParams& p, int r0, int R, int k0, int kend, int tid, uint4 (&reg)[4]) {
+__device__ __forceinline__ void xform_request(const GemmParams& p, int r0, int R, int k0, int kend, int tid, XfGate& xg) {
+  if (!p.xf_gate) return;                // launch-uniform
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    int pix, ch;
+    if (!TRANS) { pix = r0 + (c >> 3); ch = k0 + (c & 7) * 8; if (pix >= R) pix = R - 1; if (ch >= kend) ch = k0; }
+    else { pix = k0 + (c >> 4); ch = r0 + (c & 15) * 8; if (pix >= kend) pix = kend - 1; if (ch >= R) ch = r0; }
+    const float* gp = p.xf_gate + (size_t)fdiv((unsigned int)pix, p.xf_dhw) * p.xf_C + ch;
+    xg.g0[i] = *reinterpret_cast<const float4*>(gp);
+    xg.g1[i] = *reinterpret_cast<const float4*>(gp + 4);
+  }
+}
+
+template <bool TRANS>
+__device__ __forceinline__ void xform_tile(const GemmParams& p, int r0, int R, int k0, int kend, int tid, uint4 (&reg)[4], const XfGate& xg) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = tid + 256 * i;
@@ -82,10 +100,8 @@ __device__ __forceinline__ void xform_tile(const GemmParams& p, int r0, int R, i
     if (!TRANS) { pix = r0 + (c >> 3); ch = k0 + (c & 7) * 8; ok = pix < R && ch < kend; if (pix >= R) pix = R - 1; if (ch >= kend) ch = k0; }
     else { pix = k0 + (c >> 4); ch = r0 + (c & 15) * 8; ok = pix < kend && ch < R; if (pix >= kend) pix = kend - 1; if (ch >= R) ch = r0; }
     const bf8 v = __builtin_bit_cast(bf8, reg[i]);
+    const float g[8] = {xg.g0[i].x, xg.g0[i].y, xg.g0[i].z, xg.g0[i].w, xg.g1[i].x, xg.g1[i].y, xg.g1[i].z, xg.g1[i].w};
     if (!p.xf_scale) {                   // launch-uniform: the operand is already activated, only the SE gate remains
-      const float* gp = p.xf_gate + (size_t)fdiv((unsigned int)pix, p.xf_dhw) * p.xf_C + ch;
-      const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
-      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
       bf8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(v[e]) * g[e]);      // masked (zero) elements stay zero
@@ -96,15 +112,9 @@ __device__ __forceinline__ void xform_tile(const GemmParams& p, int r0, int R, i
     const float4 h0 = *reinterpret_cast<const float4*>(p.xf_shift + ch), h1 = *reinterpret_cast<const float4*>(p.xf_shift + ch + 4);
     const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
     const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-    float g[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-    if (p.xf_gate) {                     // launch-uniform
-      const float* gp = p.xf_gate + (size_t)fdiv((unsigned int)pix, p.xf_dhw) * p.xf_C + ch;
-      const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
-      g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
-    }
     bf8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = f2bf(silu_f(bf2f(v[e]) * sc[e] + sh[e]) * g[e]);
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(silu_f(bf2f(v[e]) * sc[e] + sh[e]) * (p.xf_gate ? g[e] : 1.f));
     const uint4 ov = __builtin_bit_cast(uint4, o);
     const unsigned int msk = ok ? 0xffffffffu : 0u;      // out-of-range elements must stay zero (silu(shift) != 0)
     reg[i] = make_uint4(ov.x & msk, ov.y & msk, ov.z & msk, ov.w & msk);
@@ -158,10 +168,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
   uint4 ra[4], rb[4];
+  XfGate xg;
   load_tile<TA>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
   load_tile<!TB_KMAJOR>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb);
-  if (XF == 1) xform_tile<TA>(p, m0, p.M, kbeg, kend, tid, ra);
-  if (XF == 2) xform_tile<!TB_KMAJOR>(p, n0, p.N, kbeg, kend, tid, rb);
+  if (XF == 1) { xform_request<TA>(p, m0, p.M, kbeg, kend, tid, xg); xform_tile<TA>(p, m0, p.M, kbeg, kend, tid, ra, xg); }
+  if (XF == 2) { xform_request<!TB_KMAJOR>(p, n0, p.N, kbeg, kend, tid, xg); xform_tile<!TB_KMAJOR>(p, n0, p.N, kbeg, kend, tid, rb, xg); }
   store_tile<TA>(smem, tid, ra);
   store_tile<!TB_KMAJOR>(smem + OP_STAGE_BYTES, tid, rb);
   __syncthreads();
@@ -173,6 +184,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     if (t + 1 < nk) {
       load_tile<TA>(p.A, p.lda, m0, p.M, kbeg + (t + 1) * BK, kend, tid, ra);
       load_tile<!TB_KMAJOR>(p.B, p.ldb, n0, p.N, kbeg + (t + 1) * BK, kend, tid, rb);
+      if (XF == 1) xform_request<TA>(p, m0, p.M, kbeg + (t + 1) * BK, kend, tid, xg);
+      if (XF == 2) xform_request<!TB_KMAJOR>(p, n0, p.N, kbeg + (t + 1) * BK, kend, tid, xg);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -188,8 +201,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
     if (t + 1 < nk) {
-      if (XF == 1) xform_tile<TA>(p, m0, p.M, kbeg + (t + 1) * BK, kend, tid, ra);
-      if (XF == 2) xform_tile<!TB_KMAJOR>(p, n0, p.N, kbeg + (t + 1) * BK, kend, tid, rb);
+      if (XF == 1) xform_tile<TA>(p, m0, p.M, kbeg + (t + 1) * BK, kend, tid, ra, xg);
+      if (XF == 2) xform_tile<!TB_KMAJOR>(p, n0, p.N, kbeg + (t + 1) * BK, kend, tid, rb, xg);
       char* na = smem + (cur ^ 1) * STAGE_BYTES;
       store_tile<TA>(na, tid, ra);
       store_tile<!TB_KMAJOR>(na + OP_STAGE_BYTES, tid, rb);
