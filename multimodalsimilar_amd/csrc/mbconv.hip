@@ -20,6 +20,10 @@
 // walks and leave as ONE partial-slab row per block (summed by reduce_partials: no atomics, bitwise reproducible).
 #include "common.h"
 
+#ifndef DWT_ROW_UNPACK
+#define DWT_ROW_UNPACK 1     // 1: a staged row is unpacked to fp32 ONCE and feeds all its taps (the late, small-plane 5x5 layers are
+#endif                       //    VALU-bound: unpacking at every use doubled their instruction count); 0: unpack at every use
+
 struct DwTile {
   int B, Hi, Wi, Ho, Wo, C;
   int TH, TW, IH, IW;                 // output tile; staged input tile (with halo)
@@ -174,6 +178,20 @@ __global__ __launch_bounds__(256, 3) void dwt_fwd_kernel(const bf16* in, const f
 #pragma unroll 1
         for (int kh = 0; kh < K; ++kh) {
           const uint4* row = tile + ((size_t)(oy * S + kh) * g.IW + sx * 4 * S) * g.OG + u;
+#if DWT_ROW_UNPACK
+          float xin[NIN][8];
+#pragma unroll
+          for (int x = 0; x < NIN; ++x) unpackN<8>(row[(size_t)x * g.OG], xin[x]);
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            float w[8];
+            ldNf<8>(wl + ((kh * K + kw) * g.OG + u) * 8, w);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[j][e] += xin[j * S + kw][e] * w[e];
+          }
+#else
           uint4 raw[NIN];
 #pragma unroll
           for (int x = 0; x < NIN; ++x) raw[x] = row[(size_t)x * g.OG];
@@ -189,6 +207,7 @@ __global__ __launch_bounds__(256, 3) void dwt_fwd_kernel(const bf16* in, const f
               for (int e = 0; e < 8; ++e) acc[j][e] += xin[e] * w[e];
             }
           }
+#endif
         }
         const int gy = oy0 + oy;
 #pragma unroll
@@ -352,6 +371,20 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
 #pragma unroll 1
         for (int kh = 0; kh < K; ++kh) {
           const uint4* row = tile + ((size_t)(oy + K - 1 - kh) * g.IW + sx * SW) * g.OG + u;
+#if DWT_ROW_UNPACK
+          float tt[NIN][8];
+#pragma unroll
+          for (int x = 0; x < NIN; ++x) unpackN<8>(row[(size_t)x * g.OG], tt[x]);
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            float w[8];
+            ldNf<8>(wl + ((kh * K + kw) * g.OG + u) * 8, w);
+#pragma unroll
+            for (int j = 0; j < SW; ++j)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) da[j][e] += tt[j + K - 1 - kw][e] * w[e];
+          }
+#else
           uint4 raw[NIN];
 #pragma unroll
           for (int x = 0; x < NIN; ++x) raw[x] = row[(size_t)x * g.OG];
@@ -367,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
               for (int e = 0; e < 8; ++e) da[j][e] += tv[e] * w[e];
             }
           }
+#endif
         }
 #pragma unroll
         for (int j = 0; j < SW; ++j) {
@@ -413,6 +447,20 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
           for (int j = 0; j < SW; ++j) ra[j] = arow[(size_t)(sx * SW + j) * g.OG];
 #pragma unroll
           for (int x = 0; x < NIN; ++x) rd[x] = drow[(size_t)(sx * SW + x) * g.OG];
+#if DWT_ROW_UNPACK
+          float tv[NIN][8];
+#pragma unroll
+          for (int x = 0; x < NIN; ++x) unpackN<8>(rd[x], tv[x]);
+#pragma unroll
+          for (int j = 0; j < SW; ++j) {
+            float a[8];
+            unpackN<8>(ra[j], a);
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) dW[kw * 8 + e] += a[e] * tv[j + K - 1 - kw][e];
+          }
+#else
 #pragma unroll
           for (int j = 0; j < SW; ++j) {
             float a[8];
@@ -425,6 +473,7 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
               for (int e = 0; e < 8; ++e) dW[kw * 8 + e] += a[e] * tv[e];
             }
           }
+#endif
         }
       }
     }
