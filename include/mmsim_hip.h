@@ -69,6 +69,15 @@ int mmsim_gemm_bf16_xf(int xf_operand, int M, int N, int K, const void* A, int l
                        int ldc, int c_is_f32, const float* xf_scale, const float* xf_shift, const float* xf_gate,
                        int xf_hw, int split_k, int accumulate, void* stream);
 
+/* Paired launch of a layer's two backward products.  Between _begin and _end (per host thread, not nestable) the
+ * mmsim_gemm_bf16 / mmsim_gemm_bf16_xf calls that would run the generic (ragged-shape) kernel are parked instead of launched
+ * (at most two); _end launches them: a weight gradient (trans_a = 1, b_kmajor = 0, optionally xf_operand 2) followed by a
+ * data gradient (trans_a = 0, b_kmajor = 0) on the same stream as ONE launch (the two grids concatenated), anything else one
+ * by one in program order.  Results are identical to the separate launches.  The 1x1 convs of the 14x14 / 7x7 MBConv stages
+ * under cv_classifier.py:49 each fill the chip for only 1.3-2.5 rounds of tiles; their dW and dX products share one launch. */
+int mmsim_gemm_group_begin(void);
+int mmsim_gemm_group_end(void);
+
 /* Forward 1x1 conv (xf_operand 0: plain, 1: BN + SiLU (+ gate) applied to A while staged) that also ACCUMULATES the
  * train-mode BatchNorm statistics of its bf16 output into sums [2][N] (sum, sum of squares; pre-zeroed by the caller):
  * replaces conv + the statistics pass of the following nn.BatchNorm2d (timm conv_pw / conv_pwl / conv_head + bn).

@@ -142,16 +142,15 @@ __device__ __forceinline__ bf8 read_frag(const char* lds, int rbase, int ks, int
   }
 }
 
-template <bool TA, bool TB_KMAJOR, int XF = 0>   // XF: 0 none, 1 transform A, 2 transform B
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+template <bool TA, bool TB_KMAJOR, int XF>   // XF: 0 none, 1 transform A, 2 transform B
+__device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // XCD-aware bijective remap of the 1-D grid onto tiles
+  // XCD-aware bijective remap of the 1-D grid onto tiles (bid & 7 == blockIdx.x & 7 also in the paired launch: the second
+  // product's blocks start at a multiple of 8)
   const int ntiles = p.tiles_m * p.tiles_n;
   const int nwg = ntiles * p.splits;
-  const int bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   const int split = wg / ntiles, tile = wg - split * ntiles;
@@ -246,6 +245,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   }
 }
 
+template <bool TA, bool TB_KMAJOR, int XF = 0>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_body<TA, TB_KMAJOR, XF>(p, blockIdx.x, smem);
+}
+
+// Two products of one layer's backward in ONE launch: the weight gradient (A^T B, split-K; XF = 2 applies the operand transform
+// to B) in blocks [0, nwg1) and the data gradient (A B, bf16 output with its epilogue) in blocks [n1r, n1r + nwg2), n1r = nwg1
+// rounded up to 8.  At 14 x 14 / 7 x 7 each of them alone runs 1.3-2.5 rounds of tiles on the chip; together the data
+// gradient's short blocks fill the tail of the weight gradient's long ones, and a layer issues one launch instead of two.
+template <int XF>
+__global__ __launch_bounds__(256, 2) void gemm_bwd_pair_kernel(GemmParams p1, GemmParams p2, int nwg1, int n1r) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = blockIdx.x;
+  if (bid < n1r) {
+    if (bid < nwg1) gemm_body<true, false, XF>(p1, bid, smem);
+  } else {
+    gemm_body<false, false, 0>(p2, bid - n1r, smem);
+  }
+}
+
 // C-ABI -- see include/mmsim_hip.h for the contract.
 bool gemm_fast_eligible(const GemmParams& p, int splits);
 void gemm_fast_launch(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s);
@@ -254,6 +274,40 @@ static bool force_generic() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("MMSIM_GEMM_GENERIC"); v = (e && e[0] == '1') ? 1 : 0; }
   return v == 1;
+}
+
+// ---- paired launches (mmsim_gemm_group_begin / _end): see gemm_bwd_pair_kernel
+struct GroupItem { GemmParams p; int trans_a, b_kmajor, xf, nwg; hipStream_t s; };
+struct GroupState { bool active = false; int n = 0; GroupItem item[2]; };
+static thread_local GroupState g_group;
+static int launch_generic(const GemmParams& p, int trans_a, int b_kmajor, int xf_operand, int nwg, hipStream_t s);
+static void generic_attr_optin();
+
+static int group_flush() {
+  GroupState& g = g_group;
+  const int n = g.n;
+  g.n = 0;
+  if (n == 2) {
+    const GroupItem &a = g.item[0], &b = g.item[1];
+    const bool wgrad_first = a.trans_a && !a.b_kmajor && (a.xf == 0 || a.xf == 2);
+    const bool dgrad_second = !b.trans_a && !b.b_kmajor && b.xf == 0;
+    if (wgrad_first && dgrad_second && a.s == b.s) {
+      hipStream_t s = a.s;
+      generic_attr_optin();
+      const int n1r = (a.nwg + 7) & ~7;
+      dim3 grid(n1r + b.nwg), block(256);
+      const size_t lds = 2 * STAGE_BYTES;
+      if (a.xf == 2) hipLaunchKernelGGL((gemm_bwd_pair_kernel<2>), grid, block, lds, s, a.p, b.p, a.nwg, n1r);
+      else hipLaunchKernelGGL((gemm_bwd_pair_kernel<0>), grid, block, lds, s, a.p, b.p, a.nwg, n1r);
+      return mmsim_check_launch("gemm_bwd_pair");
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    const GroupItem& it = g.item[i];
+    const int rc = launch_generic(it.p, it.trans_a, it.b_kmajor, it.xf, it.nwg, it.s);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B,
@@ -304,9 +358,24 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   const size_t lds = 2 * STAGE_BYTES;
   hipStream_t s = (hipStream_t)stream;
   if (xf_operand == 0 && !stats && !force_generic() && gemm_fast_eligible(p, splits)) {
+    if (g_group.active) { const int rc = group_flush(); if (rc) return rc; }
     gemm_fast_launch(p, trans_a, b_kmajor, splits, s);
     return mmsim_check_launch("gemm_bf16_fast");
   }
+  if (g_group.active) {                 // inside mmsim_gemm_group_begin / _end: generic-path products are parked, not launched
+    if (g_group.n < 2 && !stats) {
+      GroupItem& it = g_group.item[g_group.n++];
+      it.p = p; it.trans_a = trans_a; it.b_kmajor = b_kmajor; it.xf = xf_operand; it.nwg = (int)grid.x; it.s = s;
+      return 0;
+    }
+    const int rc = group_flush();      // anything else keeps program order: what is parked goes first
+    if (rc) return rc;
+  }
+  return launch_generic(p, trans_a, b_kmajor, xf_operand, (int)grid.x, s);
+}
+
+static void generic_attr_optin() {
+  const size_t lds = 2 * STAGE_BYTES;
   static unsigned long long attr_done = 0;          // per device
   const int dev = mmsim_current_device();
   if (!((attr_done >> dev) & 1)) {   // 80 KiB of dynamic LDS per block needs the opt-in on every instantiation
@@ -316,8 +385,16 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bwd_pair_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bwd_pair_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done |= 1ull << dev;
   }
+}
+
+static int launch_generic(const GemmParams& p, int trans_a, int b_kmajor, int xf_operand, int nwg, hipStream_t s) {
+  generic_attr_optin();
+  const size_t lds = 2 * STAGE_BYTES;
+  dim3 grid(nwg), block(256);
   if (xf_operand == 1) {
     hipLaunchKernelGGL((gemm_bf16_kernel<false, true, 1>), grid, block, lds, s, p);
   } else if (xf_operand == 2) {
@@ -332,6 +409,21 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
     hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, lds, s, p);
   }
   return mmsim_check_launch("gemm_bf16");
+}
+
+// Products issued between _begin and _end on the calling thread that take the generic kernel are parked (at most two) and
+// launched by _end: a (weight gradient, data gradient) pair as ONE launch of gemm_bwd_pair_kernel, anything else one by one in
+// program order.  Any other product (fast path, BatchNorm-statistics epilogue) first flushes what is parked.
+extern "C" int mmsim_gemm_group_begin(void) {
+  MMSIM_REQUIRE(!g_group.active, "gemm_group_begin: a group is already open on this thread");
+  g_group.active = true; g_group.n = 0;
+  return 0;
+}
+extern "C" int mmsim_gemm_group_end(void) {
+  MMSIM_REQUIRE(g_group.active, "gemm_group_end: no open group");
+  const int rc = group_flush();
+  g_group.active = false;
+  return rc;
 }
 
 extern "C" int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B,

@@ -448,15 +448,16 @@ class EfficientNet(nn.Module):
         self._bn_bwd(st, n + "." + p_bn, dx, bs.z3, P_out, b.cout, dz3, act=False)
         sc2, sh2 = self._bnp(st, n + "." + d_bn, 2), self._bnp(st, n + "." + d_bn, 3)
         gw3 = G(pw + ".weight").view(b.cout, b.mid)
-        if getattr(bs, "a2", None) is not None:
-            lib.gemm_bf16_xf(2, b.cout, b.mid, P_out, dz3.data_ptr(), b.cout, bs.a2.data_ptr(), b.mid, gw3.data_ptr(), b.mid, 1,
-                             None, None, bs.gate.data_ptr(), Ho * Wo, ops.pick_split_k(b.cout, b.mid, P_out), 1, s)
-        else:
-            lib.gemm_bf16_xf(2, b.cout, b.mid, P_out, dz3.data_ptr(), b.cout, bs.z2.data_ptr(), b.mid, gw3.data_ptr(), b.mid, 1,
-                             sc2.data_ptr(), sh2.data_ptr(), bs.gate.data_ptr(), Ho * Wo,
-                             ops.pick_split_k(b.cout, b.mid, P_out), 1, s)
         da2g = E(P_out, b.mid)
-        ops.gemm(dz3, SV(pw + ".weight", (b.cout, b.mid)), da2g, b_kmajor=False)
+        with ops.gemm_group():       # dW3 and d(a2*gate) share one launch
+            if getattr(bs, "a2", None) is not None:
+                lib.gemm_bf16_xf(2, b.cout, b.mid, P_out, dz3.data_ptr(), b.cout, bs.a2.data_ptr(), b.mid, gw3.data_ptr(), b.mid, 1,
+                                 None, None, bs.gate.data_ptr(), Ho * Wo, ops.pick_split_k(b.cout, b.mid, P_out), 1, s)
+            else:
+                lib.gemm_bf16_xf(2, b.cout, b.mid, P_out, dz3.data_ptr(), b.cout, bs.z2.data_ptr(), b.mid, gw3.data_ptr(), b.mid, 1,
+                                 sc2.data_ptr(), sh2.data_ptr(), bs.gate.data_ptr(), Ho * Wo,
+                                 ops.pick_split_k(b.cout, b.mid, P_out), 1, s)
+            ops.gemm(dz3, SV(pw + ".weight", (b.cout, b.mid)), da2g, b_kmajor=False)
         # one pass over (z2, da2g): dgate for the SE backward + the partial sums of the depthwise BN's backward statistics
         out5 = E(5, B, b.mid, dt=torch.float32)
         mu2, rs2 = self._bnp(st, n + "." + d_bn, 0), self._bnp(st, n + "." + d_bn, 1)
@@ -522,11 +523,12 @@ class EfficientNet(nn.Module):
                 dz1 = E(P_in, b.mid)
                 self._bn_bwd(st, en, dpre1, bs.z1, P_in, b.mid, dz1, act=False, sums_ready=True)
                 del dpre1
-                ops.gemm(dz1, bs.x_in, G(n + ".conv_pw.weight").view(b.mid, b.cin), trans_a=True, b_kmajor=False,
-                         split_k=ops.pick_split_k(b.mid, b.cin, P_in), accumulate=True)
                 dx_in = E(P_in, b.cin)
-                ops.gemm(dz1, SV(n + ".conv_pw.weight", (b.mid, b.cin)), dx_in, b_kmajor=False,
-                         epilogue=ops.EPI_ADD if b.skip else ops.EPI_NONE, aux_in=dx if b.skip else None)
+                with ops.gemm_group():       # dW1 and dx share one launch
+                    ops.gemm(dz1, bs.x_in, G(n + ".conv_pw.weight").view(b.mid, b.cin), trans_a=True, b_kmajor=False,
+                             split_k=ops.pick_split_k(b.mid, b.cin, P_in), accumulate=True)
+                    ops.gemm(dz1, SV(n + ".conv_pw.weight", (b.mid, b.cin)), dx_in, b_kmajor=False,
+                             epilogue=ops.EPI_ADD if b.skip else ops.EPI_NONE, aux_in=dx if b.skip else None)
         elif not fused:
             dx_in = E(P_in, b.cin)
             lib.dwconv_bwd_data(dz2.data_ptr(), bs.wT.data_ptr(), None, None, None, None, None,
@@ -560,10 +562,11 @@ class EfficientNet(nn.Module):
         lib.broadcast_pool_grad(dpooled.data_ptr(), dyh.data_ptr(), B, H * W, a.head, s)
         dzh = E(P, a.head)
         self._bn_bwd(st, "bn2", dyh, st.zh, P, a.head, dzh, act=True)
-        ops.gemm(dzh, st.x_last, G("conv_head.weight").view(a.head, a.last), trans_a=True, b_kmajor=False,
-                 split_k=ops.pick_split_k(a.head, a.last, P), accumulate=True)
         dx = E(P, a.last)
-        ops.gemm(dzh, SV("conv_head.weight", (a.head, a.last)), dx, b_kmajor=False)
+        with ops.gemm_group():
+            ops.gemm(dzh, st.x_last, G("conv_head.weight").view(a.head, a.last), trans_a=True, b_kmajor=False,
+                     split_k=ops.pick_split_k(a.head, a.last, P), accumulate=True)
+            ops.gemm(dzh, SV("conv_head.weight", (a.head, a.last)), dx, b_kmajor=False)
         del dyh, dzh
         # ---- blocks, last to first
         for b, bs in zip(reversed(a.blocks), reversed(st.blocks)):

@@ -161,6 +161,28 @@ def wgrad_pair_eligible(M1, M2, N, K):
     return M1 % 256 == 0 and M2 % 256 == 0 and N % 256 == 0 and K % 64 == 0 and (M1 + M2) // 256 * (N // 256) >= 32
 
 
+class gemm_group:
+    """`with ops.gemm_group():` -- the (weight gradient, data gradient) products issued inside leave as one launch when both
+    take the generic kernel (mmsim_gemm_group_begin / _end); MMSIM_GEMM_GROUP=0 turns the pairing off."""
+    _on = os.environ.get("MMSIM_GEMM_GROUP", "1") != "0"
+
+    def __enter__(self):
+        if self._on:
+            lib.gemm_group_begin()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self._on:
+            if et is None:
+                lib.gemm_group_end()
+            else:            # do not mask the original error with a second one
+                try:
+                    lib.gemm_group_end()
+                except Exception:
+                    pass
+        return False
+
+
 def gemm_wgrad_pair(a1, b1, c1, a2, b2, c2, split_k):
     """c1[M1,N] += a1^T b1 and c2[M2,N] += a2^T b2 in one launch (a: [K, M], b: [K, N] bf16; c: f32); see mmsim_gemm_bf16_wgrad_pair."""
     for t, n in ((a1, "a1"), (b1, "b1"), (a2, "a2"), (b2, "b2")):

@@ -514,3 +514,47 @@ def test_squeeze_that_keeps_the_activation_and_gate_only_operand():
     from multimodalsimilar_amd._lib import MmsimError
     with pytest.raises(MmsimError):                  # neither scale/shift nor a gate: rejected before launch
         lib.gemm_bf16_xf(1, P, Cout, Cin, a2.data_ptr(), Cin, w3.data_ptr(), Cin, out.data_ptr(), Cout, 0, None, None, None, HW, 1, 0, s)
+
+
+@pytest.mark.parametrize("P,Cin,Cout,HW,xf", [(1568, 200, 72, 49, 2), (1568, 200, 72, 49, 0), (392, 1632, 272, 49, 2), (6272, 112, 672, 196, 0)])
+def test_paired_backward_products_equal_the_separate_launches(P, Cin, Cout, HW, xf):
+    """mmsim_gemm_group_begin/_end: the (weight gradient, data gradient) pair of a 1x1 conv as one launch gives exactly the
+    results of the two launches (split-K 1, so no atomic-order noise), with and without the gated operand transform."""
+    from multimodalsimilar_amd import ops
+    lib, s = _lib()
+    dy = rnd(P, Cout, seed=1).bfloat16()
+    xin = rnd(P, Cin, seed=2).bfloat16()
+    gate = torch.sigmoid(rnd(P // HW, Cin, seed=3))
+    w = rnd(Cout, Cin, seed=4, scale=0.2).bfloat16()
+    res = torch.randn(P, Cin, device=DEV).bfloat16()
+
+    def run(grouped):
+        gw = torch.zeros(Cout, Cin, device=DEV)
+        dx = torch.empty(P, Cin, dtype=torch.bfloat16, device=DEV)
+        if grouped:
+            lib.gemm_group_begin()
+        if xf == 2:
+            lib.gemm_bf16_xf(2, Cout, Cin, P, dy.data_ptr(), Cout, xin.data_ptr(), Cin, gw.data_ptr(), Cin, 1, None, None,
+                             gate.data_ptr(), HW, 1, 1, s)
+        else:
+            ops.gemm(dy, xin, gw, trans_a=True, b_kmajor=False, split_k=1, accumulate=True)
+        ops.gemm(dy, w, dx, b_kmajor=False, epilogue=ops.EPI_ADD, aux_in=res)
+        if grouped:
+            lib.gemm_group_end()
+        torch.cuda.synchronize()
+        return gw, dx
+
+    gw0, dx0 = run(False)
+    gw1, dx1 = run(True)
+    assert torch.equal(gw0, gw1) and torch.equal(dx0, dx1)
+    a = xin.float() if xf == 0 else (xin.float().view(P // HW, HW, Cin) * gate.unsqueeze(1)).reshape(P, Cin)
+    assert relerr(gw1, dy.float().t() @ a) < 1.5e-2
+    assert relerr(dx1, dy.float() @ w.float() + res.float()) < 1.5e-2
+    # a group that is not a (wgrad, dgrad) pair falls back to program-order launches; an unmatched _end is an error
+    lib.gemm_group_begin()
+    ops.gemm(dy, w, dx1, b_kmajor=False)
+    lib.gemm_group_end()
+    torch.cuda.synchronize()
+    assert relerr(dx1, dy.float() @ w.float()) < 1.5e-2
+    with pytest.raises(RuntimeError):
+        lib.gemm_group_end()
