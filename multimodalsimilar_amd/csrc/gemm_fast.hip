@@ -234,9 +234,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
   // Tiles are walked in bands of p.band tile-rows, column by column inside a band: the ~32 tiles an XCD runs at once then
   // share band A panels (which stay in its 4-MiB L2 for the whole band) and 32/band B panels, instead of one tile-row
   // streaming every B panel through L2 (row-major order: PMC FETCH_SIZE was 5x the operand bytes on the QKV product).
-  const int band = tile / (p.band * p.tiles_n), within = tile - band * (p.band * p.tiles_n);
-  const int rows = min(p.band, p.tiles_m - band * p.band);
-  const int tn = within / rows, tm = band * p.band + (within - tn * rows);
+  int tm, tn;
+  if (p.band > 0) {
+    const int band = tile / (p.band * p.tiles_n), within = tile - band * (p.band * p.tiles_n);
+    const int rows = min(p.band, p.tiles_m - band * p.band);
+    tn = within / rows; tm = band * p.band + (within - tn * rows);
+  } else {
+    // column groups of -p.band tile-columns, row by row inside a group: an XCD keeps its group's B panels (the weights: -band x
+    // 512 KiB at K = 1024) in L2 for its whole chunk and streams each A panel once per group
+    const int cg = -p.band;
+    const int grp = tile / (cg * p.tiles_m), within = tile - grp * (cg * p.tiles_m);
+    const int cols = min(cg, p.tiles_n - grp * cg);
+    tm = within / cols; tn = grp * cg + (within - tm * cols);
+  }
   // grouped launch: the tile-rows past tiles_m1 are the second product's (workgroup-uniform switch of the operand pointers)
   const bool second = GRP && tm >= p.tiles_m1;
   const bf16* gA = second ? p.A2 : p.A;
@@ -379,9 +389,9 @@ static void launch_pipe(GemmParams p, int trans_a, int b_kmajor, int splits, hip
     done |= 1ull << dev;
   }
   {
-    static int band = -1;            // MMSIM_GEMM_BAND: tile-rows per band of the tile walk (1 = row-major)
-    if (band < 0) { const char* e = getenv("MMSIM_GEMM_BAND"); band = e ? atoi(e) : 8; if (band < 1) band = 1; }
-    p.band = band;
+    static int band = -1000;         // MMSIM_GEMM_BAND: tile-rows per band of the tile walk (1 = row-major); negative: column groups
+    if (band == -1000) { const char* e = getenv("MMSIM_GEMM_BAND"); band = e ? atoi(e) : 8; if (band == 0) band = 1; }
+    p.band = (band < 0 && trans_a) ? 8 : band;       // column groups (negative) only for the activation-times-weight products
   }
   if (!trans_a && b_kmajor) hipLaunchKernelGGL((gemm_pp64_kernel<false, true, BN>), grid, block, lds, s, p);
   else if (!trans_a && !b_kmajor) hipLaunchKernelGGL((gemm_pp64_kernel<false, false, BN>), grid, block, lds, s, p);

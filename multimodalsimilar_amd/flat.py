@@ -79,6 +79,28 @@ class FlatBuffer:
             ops.cast_to_bf16(self.master, self.shadow)
             self._shadow_version = v
 
-    def zero_grad(self):
-        if self.grad is not None:
+    def zero_grad(self, lazy=False):
+        """Zero the gradient buffer.  lazy=True (the training step's own zero_grad of a buffer whose ONLY writer can overwrite,
+        see take_zero_pending) only marks it: the next writer overwrites instead of accumulating and the 1.1 GB fill + read of
+        the ArcFace head's gradient never happen; any other reader calls materialize_zero() first."""
+        if self.grad is None:
+            return
+        if lazy and self.overwrite_capable:
+            self.zero_pending = True
+            return
+        self.zero_pending = False
+        self.grad.zero_()
+
+    # a lazily zeroed buffer: True between zero_grad(lazy=True) and the first writer / reader
+    zero_pending = False
+    overwrite_capable = False          # set by the owning module when one full-buffer writer produces the whole gradient
+
+    def take_zero_pending(self):
+        """Called by the (single, full-coverage) writer: True = write with overwrite semantics, the buffer counts as zeroed."""
+        p, self.zero_pending = self.zero_pending, False
+        return p
+
+    def materialize_zero(self):
+        if self.zero_pending and self.grad is not None:
             self.grad.zero_()
+        self.zero_pending = False

@@ -41,6 +41,7 @@ class ArcMarginProduct(nn.Module):
         w = self._flat.view("weight")
         nn.init.xavier_uniform_(w)                                                   # arcface.py:25
         self.weight = nn.Parameter(w)
+        self._flat.overwrite_capable = self._flat.total == w.numel()      # the dW product covers the whole gradient buffer
         self.easy_margin = easy_margin
         self.cos_m, self.sin_m, self.th, self.mm = _margin_consts(m)                 # arcface.py:28-33
         self._scratch = {}
@@ -59,6 +60,7 @@ class ArcMarginProduct(nn.Module):
         self._flat.apply_(fn)
         self.weight.data = self._flat.view("weight")
         self.weight.grad = None
+        self._flat.overwrite_capable = self._flat.total == self._flat.view("weight").numel()    # no padding outside `weight`
         self._scratch = {}
         self._wh_key = None
         return self
@@ -147,15 +149,17 @@ class ArcMarginProduct(nn.Module):
             dxh.zero_()
         ops.gemm(dcos[:, :C], st["wh"], dxh, b_kmajor=False, split_k=sk, accumulate=sk > 1)
         ops.l2norm_bwd(st["x"], st["inv_x"], dxh, 0, dx)
+        # this product writes every element of the head's gradient buffer: after a lazy zero_grad it overwrites (no fill, no read)
+        acc = not self._flat.take_zero_pending()
         if cos is not None and _FUSED_DW:
             rowvec = self._buf("rowvec", (2, C), torch.float32)
             ops.lib.arcface_rowfix(dcos.data_ptr(), cos.data_ptr(), ldc, st["inv_w"].data_ptr(), rowvec.data_ptr(), B, C, ops._stream())
             ops.gemm(dcos[:, :C], st["xh"], self._flat.gview("weight").view(C, D), trans_a=True, b_kmajor=False, bias=rowvec,
-                     epilogue=ops.EPI_ROWFIX, aux_in=st["wh"], accumulate=True)
+                     epilogue=ops.EPI_ROWFIX, aux_in=st["wh"], accumulate=acc)
         else:
             dwh = self._buf("dwh", (C, D), torch.float32)
             ops.gemm(dcos[:, :C], st["xh"], dwh, trans_a=True, b_kmajor=False)           # dWh = dcos^T @ xh
-            ops.l2norm_bwd(self.weight.detach(), st["inv_w"], dwh, 0, self._flat.gview("weight"), accumulate=True)
+            ops.l2norm_bwd(self.weight.detach(), st["inv_w"], dwh, 0, self._flat.gview("weight"), accumulate=acc)
         if self.grad_ready_hook:
             self.grad_ready_hook(self._flat, 0, self._flat.total)
         return dx

@@ -66,9 +66,9 @@ class FusedAdamW(torch.optim.Optimizer):
         # step-dependent scalars of an update captured in a hipGraph (train.GraphedTrainStep writes it before every replay)
         self.dev_hyper = None
 
-    def zero_grad(self, set_to_none=False):
+    def zero_grad(self, set_to_none=False, lazy=False):
         for f in self.flats:
-            f.zero_grad()
+            f.zero_grad(lazy=lazy)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -80,6 +80,7 @@ class FusedAdamW(torch.optim.Optimizer):
             if f.grad is None:
                 continue          # never produced a gradient: skipped like torch skips grad-is-None params
             f.ensure_device_state()
+            f.materialize_zero()          # lazily zeroed and never written since: the update must see zeros
             mv = self._mv.get(id(f))
             if mv is None or mv[0].device != f.master.device:
                 mv = (torch.zeros_like(f.master), torch.zeros_like(f.master))

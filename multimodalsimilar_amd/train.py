@@ -179,7 +179,7 @@ class TrainStep:
         self.opt_emb.step()
         self.opt_emb.zero_grad()
         self.opt_fc.step()
-        self.opt_fc.zero_grad()
+        self.opt_fc.zero_grad(lazy=True)        # the head's dW product overwrites its whole buffer next step (flat.zero_grad)
         return loss.detach(), pred
 
     def _advance(self):

@@ -424,3 +424,46 @@ def test_grouped_weight_gradient_pair(M1, M2, N, K, sk):
     assert relerr(c1, r1) < 2e-3 and relerr(c2, r2) < 2e-3
     with pytest.raises(Exception):
         ops.gemm_wgrad_pair(a1[:, :100], b1, c1[:100], a2, b2, c2, sk)
+
+
+def test_head_gradient_after_a_lazy_zero_grad_equals_the_eager_one():
+    """optimizer.zero_grad(lazy=True) marks the head's gradient buffer instead of filling it; the dW product then overwrites.
+    Gradients and updates must equal the eager zero_grad path bit for bit (C, D small: one tile path, no atomics), a second
+    backward before the step accumulates, and a step with no backward in between sees zeros."""
+    from multimodalsimilar_amd import head as H
+    from multimodalsimilar_amd.optim import FusedAdamW
+    x = rnd(8, 72, seed=5)
+    label = torch.arange(8, device=DEV) * 3
+
+    def run(lazy):
+        torch.manual_seed(0)
+        mod = H.ArcMarginProduct(72, 50, m=0.3).to(DEV)
+        opt = FusedAdamW(mod, lr=1e-2)
+        grads = []
+        for it in range(3):
+            loss, _ = mod.forward_loss(x.clone().requires_grad_(True), label)
+            loss.backward()
+            grads.append(mod.weight.grad.clone())
+            opt.step(); opt.zero_grad(lazy=lazy)
+            assert mod._flat.zero_pending == lazy
+        return mod, opt, grads
+
+    m0, o0, g0 = run(False)
+    m1, o1, g1 = run(True)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    assert torch.equal(m0.weight.detach(), m1.weight.detach())
+    # two backwards before a step: the first overwrites the stale buffer, the second accumulates
+    loss, _ = m1.forward_loss(x.clone().requires_grad_(True), label); loss.backward()
+    one = m1.weight.grad.clone()
+    loss, _ = m1.forward_loss(x.clone().requires_grad_(True), label); loss.backward()
+    assert relerr(m1.weight.grad, 2 * one) < 1e-6
+    # a step right after a lazy zero_grad (no backward): the update sees zeros, not the stale gradient
+    o1.zero_grad(lazy=True)
+    w_before = m1.weight.detach().clone()
+    o1.step()
+    assert float(m1._flat.grad.abs().max()) == 0.0 and not m1._flat.zero_pending
+    o0.zero_grad(); loss, _ = m0.forward_loss(x.clone().requires_grad_(True), label); loss.backward()
+    loss, _ = m0.forward_loss(x.clone().requires_grad_(True), label); loss.backward()
+    o0.zero_grad(); o0.step()
+    assert torch.equal(m0.weight.detach(), m1.weight.detach()) and not torch.equal(w_before, m1.weight.detach())

@@ -127,3 +127,25 @@ def test_cv_loop_schedule_and_margin_annealing_follow_the_reference_objects():
     with pytest.raises(ValueError):
         from multimodalsimilar_amd.optim import FusedAdam
         FusedAdam(model, weight_decay=0.01)
+
+
+def test_flat_buffer_lazy_zero_grad_flag():
+    """flat.zero_grad(lazy=True): only a buffer whose owner declared a full-coverage overwriting writer is marked instead of
+    filled; the writer takes the mark exactly once; a reader that needs zeros materialises them."""
+    import torch
+    from multimodalsimilar_amd.flat import FlatBuffer
+    f = FlatBuffer([("weight", (4, 8))], device="cpu")
+    f.grad = torch.ones(f.total)
+    f.zero_grad(lazy=True)
+    assert not f.zero_pending and float(f.grad.sum()) == 0          # not overwrite-capable: eager fill
+    f.grad.fill_(1)
+    f.overwrite_capable = True
+    f.zero_grad(lazy=True)
+    assert f.zero_pending and float(f.grad.sum()) == f.total        # untouched, marked
+    assert f.take_zero_pending() and not f.take_zero_pending()
+    f.zero_grad(lazy=True)
+    f.materialize_zero()
+    assert float(f.grad.sum()) == 0 and not f.zero_pending
+    f.grad.fill_(1)
+    f.zero_grad()                                                   # the default stays eager
+    assert float(f.grad.sum()) == 0 and not f.zero_pending
