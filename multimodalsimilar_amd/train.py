@@ -267,6 +267,11 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         t_emb, t_fc = ts.opt_emb._t, ts.opt_fc._t
+        # the gradient state every replay starts from: zero, and -- for a buffer whose only writer overwrites (flat.zero_grad) --
+        # marked so; without this a capture taken before any eager step would record the head's dW product as an accumulation
+        for f in list(ts.opt_emb.flats) + list(ts.opt_fc.flats):
+            f.materialize_zero()
+            f.zero_grad(lazy=True)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss, self.pred = ts._body(self.static)

@@ -84,3 +84,28 @@ def test_graph_replay_draws_new_dropout_masks_every_step():
             g.close()
     assert max(losses[False]) - min(losses[False]) < 1e-3 * abs(losses[False][0])                   # BatchNorm running stats only
     assert len(set(losses[True])) == 4 and max(losses[True]) - min(losses[True]) > 1e-3             # a new mask per replay
+
+
+def test_capture_starts_from_a_canonical_gradient_state(deterministic):
+    """The head's gradient buffer is zeroed lazily by the step (flat.zero_grad(lazy=True): the dW product overwrites).  A capture
+    taken while the buffer is NOT marked (really zero: e.g. right after a checkpoint load or a manual zero_grad) must not record
+    an accumulating dW product -- replays would then sum the gradients of all steps."""
+    from multimodalsimilar_amd import train as T
+    cfg = dict(kind="nlp", text="tiny", seq_len=32, batch=16, classes=64)
+    steps, total = 6, 12
+    batches = [T.synthetic_batch(cfg, "cuda", seed=50 + i) for i in range(steps)]
+    m1 = _model(cfg, False)
+    ts1 = T.TrainStep(m1, cfg["kind"], total)
+    eager = [ts1.step(b)[0].item() for b in batches]
+    m2 = _model(cfg, False)
+    ts2 = T.TrainStep(m2, cfg["kind"], total)
+    got = [ts2.step(b)[0].item() for b in batches[:2]]
+    for f in ts2.opt_fc.flats:
+        assert f.zero_pending                       # the step left the head's buffer marked, not filled
+        f.materialize_zero()                        # ... now it is really zero and unmarked
+    g = T.GraphedTrainStep(ts2, batches[2], warmup=0)
+    try:
+        got += [g.step(b)[0].item() for b in batches[2:]]
+    finally:
+        g.close()
+    assert max(abs(a - b) for a, b in zip(got, eager)) < 1e-5 * abs(eager[0]), (got, eager)
