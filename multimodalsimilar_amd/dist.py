@@ -15,11 +15,14 @@ from .optim import collect_flat_buffers
 
 
 class GradientExchange:
-    def __init__(self, modules, bucket_bytes=64 << 20, process_group=None):
+    def __init__(self, modules, bucket_bytes=64 << 20, process_group=None, always_exchange=False):
         self.flats = collect_flat_buffers(modules, dp_only=True)
         self.bucket_bytes = bucket_bytes
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # always_exchange: issue the collectives even in a one-rank group (a sum over one rank changes nothing): lets a one-GPU
+        # box execute the RCCL calls and their stream ordering (tests/test_gpu_ddp_equiv.py)
+        self._active = self.world > 1 or (always_exchange and dist.is_initialized())
         self._pending = {}      # id(flat) -> [start, end) waiting to be sent
         self._handles = []
         self._sent = {}         # id(flat) -> list of (start, end) already all-reduced this step
@@ -34,7 +37,7 @@ class GradientExchange:
         return 1.0 / self.world
 
     def _launch(self, flat, start, end):
-        if self.world == 1 or end <= start:
+        if not self._active or end <= start:
             return
         t = flat.grad[start:end]
         if t.is_cuda and dist.get_backend(self.pg) == "gloo":
@@ -48,7 +51,7 @@ class GradientExchange:
 
     def _on_ready(self, flat, start, end):
         """Called from a tower's backward when flat.grad[start:end] is final."""
-        if self.world == 1:
+        if not self._active:
             return
         cur = self._pending.get(id(flat))
         if cur is not None and (cur[1] == start or cur[0] == end):      # contiguous with the pending range: merge
@@ -64,7 +67,7 @@ class GradientExchange:
 
     def finish(self):
         """After loss.backward(): send whatever was not reported through hooks, then wait for everything."""
-        if self.world > 1:
+        if self._active:
             if any(f.grad is not None and f.grad.is_cuda for f in self.flats):
                 from . import ops
                 ops.join_side_streams()     # ranges launched below may have been written on a tower's side stream

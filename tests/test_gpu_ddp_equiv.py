@@ -72,3 +72,56 @@ def test_two_ranks_equal_one_process_on_the_whole_batch(tmp_path, backend):
         assert diff < 0.05 * upd + 1e-9, (k, diff, upd)     # ... and both ways of running it moved it the same way
         checked += 1
     assert checked == 5
+
+
+def _worker_rccl_one_rank(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from multimodalsimilar_amd import train as T
+    from multimodalsimilar_amd.dist import GradientExchange
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    cfg = dict(T.CONFIGS["tiny"])
+    model = T.build_model(cfg, "cuda", seed=0, dropout=False)
+    ts = T.TrainStep(model, cfg["kind"], 10)
+    assert ts.exchange is None                       # one rank: TrainStep does not exchange ...
+    ts.exchange = GradientExchange(model, bucket_bytes=1 << 16, always_exchange=True)      # ... unless told to; small buckets: many collectives
+    n_coll = [0]
+    launch = ts.exchange._launch
+    def counting(flat, s, e):
+        n_coll[0] += 1
+        return launch(flat, s, e)
+    ts.exchange._launch = counting
+    for i in range(3):
+        ts.step(T.synthetic_batch(cfg, "cuda", seed=5 + i))
+    torch.cuda.synchronize()
+    assert dist.get_backend() == "nccl" and n_coll[0] >= 6, n_coll
+    torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, out)
+    dist.destroy_process_group()
+
+
+def test_rccl_collectives_execute_on_one_rank(tmp_path, monkeypatch):
+    """RCCL itself on the one GPU of this box: a one-rank "nccl" group with the exchange forced on.  Both towers' gradient ranges
+    (the image tower's are written on its side stream) go through dist.all_reduce(async_op=True) on RCCL's stream and finish();
+    a sum over one rank is the identity, so three steps must equal the plain single-process steps exactly."""
+    from multimodalsimilar_amd import ops
+    from multimodalsimilar_amd import train as T
+    out = str(tmp_path / "rccl1.pt")
+    monkeypatch.setenv("MMSIM_DETERMINISTIC", "1")            # inherited by the worker: both runs take the reproducible kernels
+    mp.spawn(_worker_rccl_one_rank, args=(_free_port(), out), nprocs=1, join=True)
+    got = torch.load(out)
+    ops.set_deterministic(True)
+    try:
+        cfg = dict(T.CONFIGS["tiny"])
+        model = T.build_model(cfg, "cuda", seed=0, dropout=False)
+        ts = T.TrainStep(model, cfg["kind"], 10)
+        for i in range(3):
+            ts.step(T.synthetic_batch(cfg, "cuda", seed=5 + i))
+        torch.cuda.synchronize()
+        ref = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    finally:
+        ops.set_deterministic(False)
+    bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+    assert not bad, bad[:5]
