@@ -268,6 +268,24 @@ int mmsim_dwtile_bwd(const void* dy, const void* z2, const float* scale2, const 
                      const void* resid, const float* w_tap_major, void* out, float* sums1, float* g_tap_major,
                      float* dgamma2, float* dbeta2, int B, int H, int W, int C, int K, float* scratch,
                      unsigned long long scratch_floats, void* stream);
+/* Projection 1x1 conv of the early MBConv stages (timm conv_pwl after bn2 + SiLU + SE under cv_classifier.py:49; conv_pw of the
+ * depthwise-separable blocks) as one streaming pass:  z3[P,cout] (bf16) = (a2[P,mid] * gate[P / HW, mid]) W3[cout,mid]^T, and the
+ * train-mode BatchNorm statistics of the bf16 output ACCUMULATED into sums [2][cout] (pre-zeroed by the caller) -- the same contract
+ * as mmsim_gemm_bf16_bnstats(xf_operand 1, gate only), for the shapes mmsim_pw_project_fwd_eligible accepts (mid <= 384,
+ * cout <= 64, HW >= the strip height: the 112^2 / 56^2 / 28^2 stages of B0-B4).  scratch: >= 128 * cout floats. */
+int mmsim_pw_project_fwd_eligible(int P, int HW, int mid, int cout);
+int mmsim_pw_project_fwd(const void* a2, const float* gate, const void* w3_bf16, void* z3, float* sums, int P, int HW, int mid,
+                         int cout, float* scratch, unsigned long long scratch_floats, void* stream);
+
+/* Backward of the same conv as one streaming pass (autograd of conv_pwl / conv_pw after bn + SiLU + SE):
+ *   da[P,mid] (bf16) = dz3[P,cout] W3[cout,mid]            -- the gradient w.r.t. the GATED activation a2 * gate
+ *   dw3[cout,mid] (fp32) += dz3^T (a2 * gate[P / HW])
+ * replacing mmsim_gemm_bf16_xf(2, ...) + mmsim_gemm_bf16(dgrad) for the shapes mmsim_pw_project_bwd_eligible accepts (the 112^2
+ * and 56^2 stages: mid <= 192, cout <= 32).  scratch: >= 64 * cout * mid floats. */
+int mmsim_pw_project_bwd_eligible(int P, int HW, int mid, int cout);
+int mmsim_pw_project_bwd(const void* dz3, const void* a2, const float* gate, const void* w3_bf16, void* da, float* dw3, int P,
+                         int HW, int mid, int cout, float* scratch, unsigned long long scratch_floats, void* stream);
+
 /* mmsim_pw_expand_bwd: the backward of an MBConv block's expand stage  x -> conv_pw (W1) -> z1 -> bn1 (train mode)  in one
  * streaming pass (timm conv_pw + bn1 under cv_classifier.py:49): dpre = dLoss/d(bn1 output) [P, mid] (what mmsim_dwtile_bwd
  * leaves), sums1 [2][mid] = bn1's backward sums.  dx [P, cin] = dz1 W1 (+ resid), dw1 [mid, cin] += dz1^T x,

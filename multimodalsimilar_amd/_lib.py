@@ -80,11 +80,14 @@ class _Lib:
 
         def call(*args):
             rc = fn(*args)
-            if restype is ctypes.c_int and name not in ("version", "device_count", "pw_expand_bwd_eligible", "get_deterministic") and rc != 0:
+            if restype is ctypes.c_int and name not in _VALUE_RETURNING and not name.endswith("_eligible") and rc != 0:
                 raise MmsimError(f"{full}: {self.last_error()} (code {rc})")
             return rc
         object.__setattr__(self, name, call)
         return call
 
+
+# entry points whose int return is a value, not a status (plus every *_eligible predicate)
+_VALUE_RETURNING = ("version", "device_count", "get_deterministic")
 
 lib = _Lib()

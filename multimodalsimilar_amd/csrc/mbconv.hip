@@ -800,6 +800,369 @@ static int launch_pw_expand_bwd(PwBwd p, float* dw1, hipStream_t s, float* scrat
   return mmsim_check_launch("pw_expand_bwd");
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Projection 1x1 conv of the early MBConv stages as ONE streaming pass (forward):
+//   z3[p][co] = sum_c (a2[p][c] * gate[p / HW][c]) * W3[co][c]       + per-channel sum / sum of squares of the bf16-rounded z3
+// At 112^2 / 56^2 / 28^2 the product is a pure HBM stream of a2 (mid <= 336 channels in, cout <= 64 out: 2 x cout FLOP per byte
+// read), and the 128 x 128-tile GEMM spends its time on tile bookkeeping (K fits one or two 64-deep steps, 50-80 % of every B tile
+// is padding): 1.5-2.6 TB/s.  Here a block walks a CONTIGUOUS range of BM-pixel strips: W3 stays in LDS for the block's lifetime,
+// the strip's a2 chunks are requested one strip ahead, multiplied by the SE gate (the image's gate row is cached in LDS and only
+// reloaded when the range enters the next image) and written k-major into LDS; the 16 x 16 x 32 MFMAs read both operands with
+// plain 16-byte fragment reads.  Statistics stay in registers until the block ends (slab + mmsim_launch_reduce).
+struct PwPrj {
+  const bf16* a2; const float* gate; const bf16* w3; bf16* z3; float* parts;
+  int P, HW, B, mid, cout, nstrips, per_block, KS;
+  FastDiv dhw;
+};
+
+template <int BM, int COUT_T, int NCH>
+__global__ __launch_bounds__(256) void pw_project_fwd_kernel(PwPrj p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int MTD = BM / 16;                            // pixel tiles per strip
+  constexpr int WM = MTD >= 4 ? 4 : MTD;                  // waves along the pixel tiles
+  constexpr int WN = 4 / WM;                              // waves along the output-channel tiles
+  constexpr int MT_W = MTD / WM, NT_W = COUT_T / WN;
+  static_assert(MT_W >= 1 && NT_W >= 1 && MT_W * WM == MTD && NT_W * WN == COUT_T, "tile split");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = p.mid >> 3;
+  const int ZP = p.KS * 64 + 16;                          // image pitch (bytes): KS*32 channels + pad
+  char* zimg = smem;                                      // [BM][KS*32] bf16: gated a2 of the strip, k-major
+  char* wimg = zimg + BM * ZP;                            // [COUT_T*16][KS*32] bf16: W3 (rows = cout, zero rows past cout)
+  float* grow = reinterpret_cast<float*>(wimg + COUT_T * 16 * ZP);      // [2][mid]: gate rows of image cur_b, cur_b + 1
+  float* red = grow + 2 * p.mid;                          // [4 waves][2][COUT_T*16]
+  for (int i = tid; i < (BM * ZP + COUT_T * 16 * ZP) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < 4 * 2 * COUT_T * 16; i += 256) red[i] = 0.f;
+  __syncthreads();
+  for (int i = tid; i < p.cout * G; i += 256) {
+    const int r = i / G, c = i - r * G;
+    *reinterpret_cast<uint4*>(wimg + r * ZP + c * 16) = *reinterpret_cast<const uint4*>(p.w3 + (size_t)r * p.mid + c * 8);
+  }
+  const int mt0 = (wave % WM) * MT_W, nt0 = (wave / WM) * NT_W;
+  float cs[NT_W][4], cq[NT_W][4];
+#pragma unroll
+  for (int n = 0; n < NT_W; ++n)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[n][e] = cq[n][e] = 0.f;
+  const int nchunks = BM * G;
+  uint4 va[NCH];
+  auto request = [&](int strip) {
+    const size_t base = (size_t)strip * BM * p.mid;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int q = min(tid + 256 * i, nchunks - 1);
+      va[i] = *reinterpret_cast<const uint4*>(p.a2 + base + (size_t)q * 8);
+    }
+  };
+  const int sbeg = blockIdx.x * p.per_block, send = min(p.nstrips, sbeg + p.per_block);
+  int cur_b = -1;
+  if (sbeg < send) request(sbeg);
+  for (int strip = sbeg; strip < send; ++strip) {
+    const int s0 = strip * BM;
+    const int b0 = (int)fdiv((unsigned)s0, p.dhw);
+    if (b0 != cur_b) {                   // block-uniform; every thread is past the previous strip's staging (its second barrier)
+      for (int i = tid; i < 2 * p.mid; i += 256) {
+        const int j = i >= p.mid, c = i - j * p.mid;
+        grow[i] = p.gate[(size_t)min(b0 + j, p.B - 1) * p.mid + c];
+      }
+      cur_b = b0;
+    }
+    __syncthreads();                     // the previous strip's MFMAs have read the Z image; the gate rows are in place
+    const int split = (b0 + 1) * p.HW - s0;              // pixels of this strip before the next image starts (HW >= BM: at most two images)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int q = tid + 256 * i;
+      if (q < nchunks) {
+        const int pix = q / G, un = q - pix * G;
+        const float* gr = grow + (pix >= split ? p.mid : 0) + un * 8;
+        const bf8 a = __builtin_bit_cast(bf8, va[i]);
+        bf8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(a[e]) * gr[e]);
+        *reinterpret_cast<bf8*>(zimg + pix * ZP + un * 16) = o;
+      }
+    }
+    __syncthreads();
+    if (strip + 1 < send) request(strip + 1);            // the next strip's loads fly under the MFMAs
+#pragma unroll
+    for (int m = 0; m < MT_W; ++m) {
+      const int mt = mt0 + m;
+      f4 acc[NT_W];
+#pragma unroll
+      for (int n = 0; n < NT_W; ++n) acc[n] = f4{0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < p.KS; ++ks) {
+        const bf8 zf = *reinterpret_cast<const bf8*>(zimg + (mt * 16 + (lane & 15)) * ZP + (ks * 4 + (lane >> 4)) * 16);
+#pragma unroll
+        for (int n = 0; n < NT_W; ++n) {
+          const bf8 wf = *reinterpret_cast<const bf8*>(wimg + ((nt0 + n) * 16 + (lane & 15)) * ZP + (ks * 4 + (lane >> 4)) * 16);
+          acc[n] = mfma16(wf, zf, acc[n]);                 // acc[e] = z3[pixel lane&15][channel 4(lane>>4)+e] of tile (mt, nt0+n)
+        }
+      }
+      const int pix = mt * 16 + (lane & 15);
+#pragma unroll
+      for (int n = 0; n < NT_W; ++n) {
+        const int co = (nt0 + n) * 16 + (lane >> 4) * 4;
+        const bf4 o = {f2bf(acc[n][0]), f2bf(acc[n][1]), f2bf(acc[n][2]), f2bf(acc[n][3])};
+        if (co < p.cout) *reinterpret_cast<bf4*>(p.z3 + ((size_t)s0 + pix) * p.cout + co) = o;      // cout % 8 == 0: the group is valid as a whole
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float v = bf2f(o[e]); cs[n][e] += v; cq[n][e] += v * v; }   // zero weight rows past cout add zeros
+      }
+    }
+  }
+  // ---- statistics of this block: lanes of one channel group (same lane >> 4) hold 16 different pixels
+#pragma unroll
+  for (int n = 0; n < NT_W; ++n)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int sh = 1; sh < 16; sh <<= 1) { cs[n][e] += __shfl_xor(cs[n][e], sh, 64); cq[n][e] += __shfl_xor(cq[n][e], sh, 64); }
+    }
+  if ((lane & 15) == 0) {
+#pragma unroll
+    for (int n = 0; n < NT_W; ++n)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = (nt0 + n) * 16 + (lane >> 4) * 4 + e;
+        red[(wave * 2 + 0) * COUT_T * 16 + co] = cs[n][e];
+        red[(wave * 2 + 1) * COUT_T * 16 + co] = cq[n][e];
+      }
+  }
+  __syncthreads();
+  if (tid < 2 * p.cout) {
+    const int which = tid >= p.cout, co = tid - which * p.cout;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) t += red[(w * 2 + which) * COUT_T * 16 + co];
+    p.parts[(size_t)blockIdx.x * 2 * p.cout + which * p.cout + co] = t;
+  }
+}
+
+template <int BM, int COUT_T, int NCH>
+static int launch_pw_project_fwd(PwPrj p, float* sums, hipStream_t s, float* scratch, unsigned long long scratch_floats) {
+  p.nstrips = p.P / BM;
+  p.KS = (p.mid + 31) / 32;
+  const int ZP = p.KS * 64 + 16;
+  const size_t lds = (size_t)BM * ZP + (size_t)COUT_T * 16 * ZP + (size_t)2 * p.mid * 4 + (size_t)4 * 2 * COUT_T * 16 * 4;
+  MMSIM_REQUIRE(lds <= 100 * 1024, "pw_project_fwd: LDS images too large");
+  MMSIM_REQUIRE(BM * (p.mid >> 3) <= 256 * NCH, "pw_project_fwd: strip too wide for the staging registers");
+  int grid = p.nstrips < 1024 ? p.nstrips : 1024;
+  while (grid > 64 && (size_t)grid * 2 * p.cout > scratch_floats) grid /= 2;
+  MMSIM_REQUIRE((size_t)grid * 2 * p.cout <= scratch_floats, "pw_project_fwd: scratch too small");
+  p.per_block = (p.nstrips + grid - 1) / grid;
+  grid = (p.nstrips + p.per_block - 1) / p.per_block;      // no empty blocks: every slab row is written
+  static unsigned long long done = 0;
+  const int dev = mmsim_current_device();
+  if (!((done >> dev) & 1)) {
+    (void)hipFuncSetAttribute((const void*)pw_project_fwd_kernel<BM, COUT_T, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    done |= 1ull << dev;
+  }
+  p.parts = scratch;
+  hipLaunchKernelGGL((pw_project_fwd_kernel<BM, COUT_T, NCH>), dim3(grid), dim3(256), lds, s, p);
+  mmsim_launch_reduce(scratch, grid, 2 * p.cout, sums, 1, s);      /* sums += (pre-zeroed by the caller) */
+  return mmsim_check_launch("pw_project_fwd");
+}
+
+// variant by shape: 0 = not eligible
+static int pw_project_variant(int P, int HW, int mid, int cout) {
+  if (P <= 0 || HW <= 0 || (P % HW) || (mid % 8) || (cout % 8)) return 0;
+  if (mid <= 48 && cout <= 32 && HW >= 256 && (P % 256) == 0) return 1;        // depthwise-separable blocks at 112^2
+  if (mid <= 192 && cout <= 32 && HW >= 64 && (P % 64) == 0) return 2;         // 56^2 stage
+  if (mid <= 192 && cout <= 64 && HW >= 32 && (P % 32) == 0) return 3;         // first 28^2 block (wider ones: the GEMM measures the same)
+  return 0;
+}
+extern "C" int mmsim_pw_project_fwd_eligible(int P, int HW, int mid, int cout) { return pw_project_variant(P, HW, mid, cout) != 0; }
+
+extern "C" int mmsim_pw_project_fwd(const void* a2, const float* gate, const void* w3_bf16, void* z3, float* sums, int P, int HW,
+                                    int mid, int cout, float* scratch, unsigned long long scratch_floats, void* stream) {
+  MMSIM_REQUIRE(a2 && gate && w3_bf16 && z3 && sums && scratch, "pw_project_fwd: null operand");
+  const int v = pw_project_variant(P, HW, mid, cout);
+  MMSIM_REQUIRE(v != 0, "pw_project_fwd: shape not eligible (see mmsim_pw_project_fwd_eligible)");
+  PwPrj p;
+  p.a2 = (const bf16*)a2; p.gate = gate; p.w3 = (const bf16*)w3_bf16; p.z3 = (bf16*)z3;
+  p.P = P; p.HW = HW; p.B = P / HW; p.mid = mid; p.cout = cout; p.dhw = make_fastdiv((unsigned)HW);
+  if (v == 1) return launch_pw_project_fwd<256, 2, 6>(p, sums, (hipStream_t)stream, scratch, scratch_floats);
+  if (v == 2) return launch_pw_project_fwd<64, 2, 6>(p, sums, (hipStream_t)stream, scratch, scratch_floats);
+  return launch_pw_project_fwd<32, 4, 6>(p, sums, (hipStream_t)stream, scratch, scratch_floats);
+}
+
+// Backward of the same conv as one streaming pass over a2:
+//   d(a2 * gate)[p][c] = sum_co dz3[p][co] W3[co][c]        (bf16 out, consumed by mmsim_pool_bn_bwd / mmsim_dwtile_bwd)
+//   dW3[co][c]        += sum_p  dz3[p][co] (a2[p][c] * gate[p / HW][c])
+// Per strip: gated a2 and dz3 into LDS images (rows = pixels); the data gradient (K = cout: one or two MFMAs per 16 x 16 tile) goes
+// through an LDS output image so that it leaves as whole 16-byte row chunks; the weight gradient reads both operands with
+// transposing LDS reads and stays in registers for the block's lifetime (slab + mmsim_launch_reduce).
+struct PwPrjBwd {
+  const bf16* dz3; const bf16* a2; const float* gate; const bf16* w3; bf16* da; float* parts;
+  int P, HW, B, mid, cout, nstrips, per_block, KS;
+  FastDiv dhw;
+};
+
+template <int BM, int COUT_T, int NCH, int NCX, int MAXW>
+__global__ __launch_bounds__(256) void pw_project_bwd_kernel(PwPrjBwd p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int MTD = BM / 16, MT_W = MTD / 4;            // pixel tiles per strip / per wave
+  constexpr int XP = COUT_T * 32 + 16;                    // dz3 image pitch (bytes)
+  constexpr int KO = COUT_T / 2;                          // 32-deep steps of the data gradient's reduction over cout
+  static_assert(MT_W >= 1 && (COUT_T % 2) == 0, "tile split");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = p.mid >> 3, XG = p.cout >> 3, NT = (p.mid + 15) >> 4;
+  const int ZP = p.KS * 64 + 16;
+  char* zimg = smem;                                      // [BM][KS*32]  gated a2 (rows = pixels)
+  char* oimg = zimg + BM * ZP;                            // [BM][KS*32]  d(a2*gate) of the strip
+  char* ximg = oimg + BM * ZP;                            // [BM][COUT_T*16]  dz3 (rows = pixels)
+  char* wimg = ximg + BM * XP;                            // [COUT_T*16][KS*32]  W3 (rows = cout)
+  float* grow = reinterpret_cast<float*>(wimg + COUT_T * 16 * ZP);      // [2][mid]
+  for (int i = tid; i < (2 * BM * ZP + BM * XP + COUT_T * 16 * ZP) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  for (int i = tid; i < p.cout * G; i += 256) {
+    const int r = i / G, c = i - r * G;
+    *reinterpret_cast<uint4*>(wimg + r * ZP + c * 16) = *reinterpret_cast<const uint4*>(p.w3 + (size_t)r * p.mid + c * 8);
+  }
+  const int nwt = COUT_T * NT;                            // weight-gradient tiles (16 x 16), dealt round-robin to the waves
+  f4 dW[MAXW];
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) dW[i] = f4{0.f, 0.f, 0.f, 0.f};
+  const int nchunks = BM * G, nxch = BM * XG;
+  uint4 va[NCH], vx[NCX];
+  auto request = [&](int strip) {
+    const size_t base = (size_t)strip * BM * p.mid, xbase = (size_t)strip * BM * p.cout;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) va[i] = *reinterpret_cast<const uint4*>(p.a2 + base + (size_t)min(tid + 256 * i, nchunks - 1) * 8);
+#pragma unroll
+    for (int i = 0; i < NCX; ++i) vx[i] = *reinterpret_cast<const uint4*>(p.dz3 + xbase + (size_t)min(tid + 256 * i, nxch - 1) * 8);
+  };
+  const int sbeg = blockIdx.x * p.per_block, send = min(p.nstrips, sbeg + p.per_block);
+  int cur_b = -1;
+  if (sbeg < send) request(sbeg);
+  for (int strip = sbeg; strip < send; ++strip) {
+    const int s0 = strip * BM;
+    const int b0 = (int)fdiv((unsigned)s0, p.dhw);
+    if (b0 != cur_b) {
+      for (int i = tid; i < 2 * p.mid; i += 256) {
+        const int j = i >= p.mid, c = i - j * p.mid;
+        grow[i] = p.gate[(size_t)min(b0 + j, p.B - 1) * p.mid + c];
+      }
+      cur_b = b0;
+    }
+    __syncthreads();                     // A: the previous strip's output image has been copied out, its MFMAs are done
+    const int split = (b0 + 1) * p.HW - s0;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int q = tid + 256 * i;
+      if (q < nchunks) {
+        const int pix = q / G, un = q - pix * G;
+        const float* gr = grow + (pix >= split ? p.mid : 0) + un * 8;
+        const bf8 a = __builtin_bit_cast(bf8, va[i]);
+        bf8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(a[e]) * gr[e]);
+        *reinterpret_cast<bf8*>(zimg + pix * ZP + un * 16) = o;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NCX; ++i) {
+      const int q = tid + 256 * i;
+      if (q < nxch) {
+        const int pix = q / XG, un = q - pix * XG;
+        *reinterpret_cast<uint4*>(ximg + pix * XP + un * 16) = vx[i];
+      }
+    }
+    __syncthreads();                     // B
+    if (strip + 1 < send) request(strip + 1);
+    // ---- d(a2*gate) = dz3 W3 into the output image: wave w owns pixel tiles w*MT_W ..., all channel tiles
+#pragma unroll
+    for (int m = 0; m < MT_W; ++m) {
+      const int mt = wave * MT_W + m;
+      bf8 xf[KO];
+#pragma unroll
+      for (int ks = 0; ks < KO; ++ks)
+        xf[ks] = *reinterpret_cast<const bf8*>(ximg + (mt * 16 + (lane & 15)) * XP + (ks * 4 + (lane >> 4)) * 16);
+      for (int nt = 0; nt < NT; ++nt) {
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KO; ++ks) acc = mfma16(tr_frag16(wimg, ZP, ks * 32, nt * 16, lane), xf[ks], acc);
+        const bf4 o = {f2bf(acc[0]), f2bf(acc[1]), f2bf(acc[2]), f2bf(acc[3])};      // [pixel lane&15][channel nt*16 + 4(lane>>4) + e]
+        *reinterpret_cast<bf4*>(oimg + (mt * 16 + (lane & 15)) * ZP + (nt * 16 + (lane >> 4) * 4) * 2) = o;
+      }
+    }
+    // ---- dW3 += dz3^T (a2*gate): tiles COUT_T x NT, reduction over the strip's pixels
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i) {
+      const int t = wave + 4 * i;
+      if (t < nwt) {                     // wave-uniform: EXEC stays all ones for the transposing reads
+        const int mt = t / NT, nt = t - mt * NT;
+#pragma unroll
+        for (int ks = 0; ks < BM / 32; ++ks)
+          dW[i] = mfma16(tr_frag16(zimg, ZP, ks * 32, nt * 16, lane), tr_frag16(ximg, XP, ks * 32, mt * 16, lane), dW[i]);
+      }
+    }
+    __syncthreads();                     // C: the output image is complete
+    {
+      bf16* dst = p.da + (size_t)s0 * p.mid;
+      for (int q = tid; q < nchunks; q += 256) {
+        const int pix = q / G, un = q - pix * G;
+        *reinterpret_cast<uint4*>(dst + (size_t)q * 8) = *reinterpret_cast<const uint4*>(oimg + pix * ZP + un * 16);
+      }
+    }
+  }
+  float* slab = p.parts + (size_t)blockIdx.x * p.cout * p.mid;
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) {
+    const int t = wave + 4 * i;
+    if (t < nwt) {
+      const int mt = t / NT, nt = t - mt * NT;
+      const int co = mt * 16 + (lane & 15), c = nt * 16 + (lane >> 4) * 4;
+      if (co < p.cout && c < p.mid) *reinterpret_cast<f4*>(slab + (size_t)co * p.mid + c) = dW[i];      // mid % 8 == 0: whole group valid
+    }
+  }
+}
+
+template <int BM, int COUT_T, int NCH, int NCX, int MAXW>
+static int launch_pw_project_bwd(PwPrjBwd p, float* dw3, hipStream_t s, float* scratch, unsigned long long scratch_floats) {
+  p.nstrips = p.P / BM;
+  p.KS = (p.mid + 31) / 32;
+  const int ZP = p.KS * 64 + 16, XP = COUT_T * 32 + 16;
+  const size_t lds = (size_t)2 * BM * ZP + (size_t)BM * XP + (size_t)COUT_T * 16 * ZP + (size_t)2 * p.mid * 4;
+  MMSIM_REQUIRE(lds <= 100 * 1024, "pw_project_bwd: LDS images too large");
+  MMSIM_REQUIRE(BM * (p.mid >> 3) <= 256 * NCH && BM * (p.cout >> 3) <= 256 * NCX, "pw_project_bwd: strip too wide for the staging registers");
+  MMSIM_REQUIRE(COUT_T * ((p.mid + 15) / 16) <= 4 * MAXW, "pw_project_bwd: weight gradient does not fit the accumulators");
+  const size_t slab = (size_t)p.cout * p.mid;
+  int grid = p.nstrips < 1024 ? p.nstrips : 1024;
+  while (grid > 64 && (size_t)grid * slab > scratch_floats) grid /= 2;
+  MMSIM_REQUIRE((size_t)grid * slab <= scratch_floats, "pw_project_bwd: scratch too small");
+  p.per_block = (p.nstrips + grid - 1) / grid;
+  grid = (p.nstrips + p.per_block - 1) / p.per_block;
+  static unsigned long long done = 0;
+  const int dev = mmsim_current_device();
+  if (!((done >> dev) & 1)) {
+    (void)hipFuncSetAttribute((const void*)pw_project_bwd_kernel<BM, COUT_T, NCH, NCX, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    done |= 1ull << dev;
+  }
+  p.parts = scratch;
+  hipLaunchKernelGGL((pw_project_bwd_kernel<BM, COUT_T, NCH, NCX, MAXW>), dim3(grid), dim3(256), lds, s, p);
+  mmsim_launch_reduce(scratch, grid, (int)slab, dw3, 1, s);      /* dW3 += */
+  return mmsim_check_launch("pw_project_bwd");
+}
+
+static int pw_project_bwd_variant(int P, int HW, int mid, int cout) {
+  if (P <= 0 || HW <= 0 || (P % HW) || (mid % 8) || (cout % 8)) return 0;
+  if (mid <= 48 && cout <= 32 && HW >= 128 && (P % 128) == 0) return 1;        // depthwise-separable blocks at 112^2
+  if (mid <= 192 && cout <= 32 && HW >= 64 && (P % 64) == 0) return 2;         // 56^2 stage
+  return 0;
+}
+extern "C" int mmsim_pw_project_bwd_eligible(int P, int HW, int mid, int cout) { return pw_project_bwd_variant(P, HW, mid, cout) != 0; }
+
+extern "C" int mmsim_pw_project_bwd(const void* dz3, const void* a2, const float* gate, const void* w3_bf16, void* da, float* dw3,
+                                    int P, int HW, int mid, int cout, float* scratch, unsigned long long scratch_floats, void* stream) {
+  MMSIM_REQUIRE(dz3 && a2 && gate && w3_bf16 && da && dw3 && scratch, "pw_project_bwd: null operand");
+  const int v = pw_project_bwd_variant(P, HW, mid, cout);
+  MMSIM_REQUIRE(v != 0, "pw_project_bwd: shape not eligible (see mmsim_pw_project_bwd_eligible)");
+  PwPrjBwd p;
+  p.dz3 = (const bf16*)dz3; p.a2 = (const bf16*)a2; p.gate = gate; p.w3 = (const bf16*)w3_bf16; p.da = (bf16*)da;
+  p.P = P; p.HW = HW; p.B = P / HW; p.mid = mid; p.cout = cout; p.dhw = make_fastdiv((unsigned)HW);
+  if (v == 1) return launch_pw_project_bwd<128, 2, 3, 2, 2>(p, dw3, (hipStream_t)stream, scratch, scratch_floats);
+  return launch_pw_project_bwd<64, 2, 6, 1, 6>(p, dw3, (hipStream_t)stream, scratch, scratch_floats);
+}
+
 extern "C" int mmsim_pw_expand_bwd_eligible(int P, int mid, int cin) {
   if (P <= 0 || (P % 64) || (mid % 8) || (cin % 8)) return 0;
   if (cin <= 32 && mid <= 192) return 1;

@@ -74,6 +74,8 @@ _KEEP_A2 = os.environ.get("MMSIM_KEEP_A2", "1") != "0"
 _DWTILE = os.environ.get("MMSIM_DWTILE", "1") != "0"
 # MMSIM_PW_FUSED=0: expand-stage backward as bn_bwd + two GEMMs instead of the one-pass mmsim_pw_expand_bwd (A/B switch)
 _PW_FUSED = os.environ.get("MMSIM_PW_FUSED", "1") != "0"
+# MMSIM_PW_PROJECT=0: projection conv of the early stages through the generic GEMM instead of the streaming kernels (A/B switch)
+_PW_PROJECT = os.environ.get("MMSIM_PW_PROJECT", "1") != "0"
 
 class _Holder(nn.Module):
     pass
@@ -353,7 +355,11 @@ class EfficientNet(nn.Module):
         bs.z3 = E(P_out, b.cout)
         w3 = SV(pw + ".weight", (b.cout, b.mid))
         sm = self._sums(st, n + "." + p_bn, "f")
-        if bs.a2 is not None:
+        if bs.a2 is not None and _PW_PROJECT and lib.pw_project_fwd_eligible(P_out, Ho * Wo, b.mid, b.cout):
+            # early stages: one streaming pass over a2 (gate applied on the way into LDS), W3 resident in LDS, statistics in registers
+            lib.pw_project_fwd(bs.a2.data_ptr(), bs.gate.data_ptr(), w3.data_ptr(), bs.z3.data_ptr(), sm.data_ptr(), P_out, Ho * Wo,
+                               b.mid, b.cout, *self._scr(), s)
+        elif bs.a2 is not None:
             lib.gemm_bf16_bnstats(1, P_out, b.cout, b.mid, bs.a2.data_ptr(), b.mid, w3.data_ptr(), b.mid, bs.z3.data_ptr(), b.cout,
                                   None, None, bs.gate.data_ptr(), Ho * Wo, sm.data_ptr(), *self._scr(), s)
         else:
@@ -449,15 +455,20 @@ class EfficientNet(nn.Module):
         sc2, sh2 = self._bnp(st, n + "." + d_bn, 2), self._bnp(st, n + "." + d_bn, 3)
         gw3 = G(pw + ".weight").view(b.cout, b.mid)
         da2g = E(P_out, b.mid)
-        with ops.gemm_group():       # dW3 and d(a2*gate) share one launch
-            if getattr(bs, "a2", None) is not None:
-                lib.gemm_bf16_xf(2, b.cout, b.mid, P_out, dz3.data_ptr(), b.cout, bs.a2.data_ptr(), b.mid, gw3.data_ptr(), b.mid, 1,
-                                 None, None, bs.gate.data_ptr(), Ho * Wo, ops.pick_split_k(b.cout, b.mid, P_out), 1, s)
-            else:
-                lib.gemm_bf16_xf(2, b.cout, b.mid, P_out, dz3.data_ptr(), b.cout, bs.z2.data_ptr(), b.mid, gw3.data_ptr(), b.mid, 1,
-                                 sc2.data_ptr(), sh2.data_ptr(), bs.gate.data_ptr(), Ho * Wo,
-                                 ops.pick_split_k(b.cout, b.mid, P_out), 1, s)
-            ops.gemm(dz3, SV(pw + ".weight", (b.cout, b.mid)), da2g, b_kmajor=False)
+        if getattr(bs, "a2", None) is not None and _PW_PROJECT and lib.pw_project_bwd_eligible(P_out, Ho * Wo, b.mid, b.cout):
+            # early stages: dW3 and d(a2*gate) out of one streaming pass over a2
+            lib.pw_project_bwd(dz3.data_ptr(), bs.a2.data_ptr(), bs.gate.data_ptr(), SV(pw + ".weight", (b.cout, b.mid)).data_ptr(),
+                               da2g.data_ptr(), gw3.data_ptr(), P_out, Ho * Wo, b.mid, b.cout, *self._scr(), s)
+        else:
+            with ops.gemm_group():       # dW3 and d(a2*gate) share one launch
+                if getattr(bs, "a2", None) is not None:
+                    lib.gemm_bf16_xf(2, b.cout, b.mid, P_out, dz3.data_ptr(), b.cout, bs.a2.data_ptr(), b.mid, gw3.data_ptr(), b.mid, 1,
+                                     None, None, bs.gate.data_ptr(), Ho * Wo, ops.pick_split_k(b.cout, b.mid, P_out), 1, s)
+                else:
+                    lib.gemm_bf16_xf(2, b.cout, b.mid, P_out, dz3.data_ptr(), b.cout, bs.z2.data_ptr(), b.mid, gw3.data_ptr(), b.mid, 1,
+                                     sc2.data_ptr(), sh2.data_ptr(), bs.gate.data_ptr(), Ho * Wo,
+                                     ops.pick_split_k(b.cout, b.mid, P_out), 1, s)
+                ops.gemm(dz3, SV(pw + ".weight", (b.cout, b.mid)), da2g, b_kmajor=False)
         # one pass over (z2, da2g): dgate for the SE backward + the partial sums of the depthwise BN's backward statistics
         out5 = E(5, B, b.mid, dt=torch.float32)
         mu2, rs2 = self._bnp(st, n + "." + d_bn, 0), self._bnp(st, n + "." + d_bn, 1)

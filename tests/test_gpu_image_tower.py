@@ -558,3 +558,59 @@ def test_paired_backward_products_equal_the_separate_launches(P, Cin, Cout, HW, 
     assert relerr(dx1, dy.float() @ w.float()) < 1.5e-2
     with pytest.raises(RuntimeError):
         lib.gemm_group_end()
+
+
+@pytest.mark.parametrize("B,HW,mid,cout", [(3, 256, 48, 24), (2, 512, 24, 24), (5, 64, 192, 32), (4, 128, 144, 32), (6, 32, 192, 56),
+                                           (3, 96, 192, 56), (2, 784, 176, 40)])
+def test_streaming_projection_forward_equals_the_gemm_form(B, HW, mid, cout):
+    """mmsim_pw_project_fwd (early-stage projection conv as one streaming pass: gate applied while staging, W3 resident in LDS,
+    BatchNorm statistics in registers) against fp32 torch and against mmsim_gemm_bf16_bnstats, the form it replaces: same
+    bf16 outputs up to the accumulation order, same statistics.  Shapes cover the three tile variants, strips that straddle two
+    images (HW not a multiple of the strip) and a partly empty channel tile (cout = 24, 56)."""
+    lib, s = _lib()
+    P = B * HW
+    assert lib.pw_project_fwd_eligible(P, HW, mid, cout)
+    a2 = rnd(P, mid, seed=1).bfloat16()
+    gate = torch.sigmoid(rnd(B, mid, seed=2))
+    w3 = rnd(cout, mid, seed=3, scale=0.2).bfloat16()
+    z3 = torch.empty(P, cout, dtype=torch.bfloat16, device=DEV)
+    sums = torch.zeros(2 * cout, device=DEV)
+    lib.pw_project_fwd(a2.data_ptr(), gate.data_ptr(), w3.data_ptr(), z3.data_ptr(), sums.data_ptr(), P, HW, mid, cout, *scr(), s)
+    a = ((a2.float().view(B, HW, mid) * gate.unsqueeze(1)).bfloat16().float()).reshape(P, mid)      # the operand as staged (bf16)
+    ref = a @ w3.float().t()
+    assert relerr(z3, ref) < 1e-2
+    assert relerr(sums[:cout], z3.float().sum(0)) < 1e-4 and relerr(sums[cout:], (z3.float() ** 2).sum(0)) < 1e-4
+    z3g = torch.empty_like(z3)
+    sums_g = torch.zeros_like(sums)
+    lib.gemm_bf16_bnstats(1, P, cout, mid, a2.data_ptr(), mid, w3.data_ptr(), mid, z3g.data_ptr(), cout, None, None, gate.data_ptr(), HW,
+                          sums_g.data_ptr(), *scr(), s)
+    assert relerr(z3, z3g) < 4e-3 and relerr(sums, sums_g) < 2e-3
+    assert not lib.pw_project_fwd_eligible(P, HW, 1632, 272) and not lib.pw_project_fwd_eligible(P, HW, mid, cout + 4)
+
+
+@pytest.mark.parametrize("B,HW,mid,cout", [(3, 256, 48, 24), (2, 384, 24, 24), (5, 64, 192, 32), (4, 128, 144, 32), (4, 96, 192, 24)])
+def test_streaming_projection_backward_equals_the_gemm_form(B, HW, mid, cout):
+    """mmsim_pw_project_bwd: d(a2*gate) = dz3 W3 and dW3 += dz3^T (a2*gate) out of one streaming pass, against fp32 torch and
+    against the two generic products it replaces (split-K 1).  Covers both tile variants, strips straddling two images and a
+    partly empty output-channel tile; dW3 is accumulated onto a non-zero buffer."""
+    from multimodalsimilar_amd import ops
+    lib, s = _lib()
+    P = B * HW
+    assert lib.pw_project_bwd_eligible(P, HW, mid, cout)
+    a2 = rnd(P, mid, seed=1).bfloat16()
+    gate = torch.sigmoid(rnd(B, mid, seed=2))
+    w3 = rnd(cout, mid, seed=3, scale=0.2).bfloat16()
+    dz3 = rnd(P, cout, seed=4).bfloat16()
+    base = rnd(cout, mid, seed=5)
+    da = torch.empty(P, mid, dtype=torch.bfloat16, device=DEV)
+    dw = base.clone()
+    lib.pw_project_bwd(dz3.data_ptr(), a2.data_ptr(), gate.data_ptr(), w3.data_ptr(), da.data_ptr(), dw.data_ptr(), P, HW, mid, cout, *scr(), s)
+    ag = ((a2.float().view(B, HW, mid) * gate.unsqueeze(1)).bfloat16().float()).reshape(P, mid)
+    assert relerr(da, dz3.float() @ w3.float()) < 1e-2
+    assert relerr(dw - base, dz3.float().t() @ ag) < 5e-3
+    da_g = torch.empty_like(da)
+    dw_g = base.clone()
+    lib.gemm_bf16_xf(2, cout, mid, P, dz3.data_ptr(), cout, a2.data_ptr(), mid, dw_g.data_ptr(), mid, 1, None, None, gate.data_ptr(), HW, 1, 1, s)
+    ops.gemm(dz3, w3, da_g, b_kmajor=False)
+    assert relerr(da, da_g) < 4e-3 and relerr(dw - base, dw_g - base) < 2e-3
+    assert not lib.pw_project_bwd_eligible(P, HW, 336, 56)
