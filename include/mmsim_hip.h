@@ -277,6 +277,14 @@ int mmsim_pw_project_fwd_eligible(int P, int HW, int mid, int cout);
 int mmsim_pw_project_fwd(const void* a2, const float* gate, const void* w3_bf16, void* z3, float* sums, int P, int HW, int mid,
                          int cout, float* scratch, unsigned long long scratch_floats, void* stream);
 
+/* Expansion 1x1 conv of the 56^2 MBConv stage (timm conv_pw under cv_classifier.py:49) as one streaming pass:
+ * z1[P,mid] (bf16) = x[P,cin] W1[mid,cin]^T and the train-mode BatchNorm statistics of the bf16 output ACCUMULATED into
+ * sums [2][mid] (pre-zeroed by the caller): the contract of mmsim_gemm_bf16_bnstats(xf_operand 0) for cin <= 32, 64 <= mid <= 192,
+ * P % 64 == 0 (mmsim_pw_expand_fwd_eligible).  scratch: >= 128 * mid floats. */
+int mmsim_pw_expand_fwd_eligible(int P, int mid, int cin);
+int mmsim_pw_expand_fwd(const void* x, const void* w1_bf16, void* z1, float* sums, int P, int mid, int cin, float* scratch,
+                        unsigned long long scratch_floats, void* stream);
+
 /* Backward of the same conv as one streaming pass (autograd of conv_pwl / conv_pw after bn + SiLU + SE):
  *   da[P,mid] (bf16) = dz3[P,cout] W3[cout,mid]            -- the gradient w.r.t. the GATED activation a2 * gate
  *   dw3[cout,mid] (fp32) += dz3^T (a2 * gate[P / HW])

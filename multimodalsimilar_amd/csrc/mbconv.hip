@@ -984,6 +984,134 @@ extern "C" int mmsim_pw_project_fwd(const void* a2, const float* gate, const voi
   return launch_pw_project_fwd<32, 4, 6>(p, sums, (hipStream_t)stream, scratch, scratch_floats);
 }
 
+// Expansion 1x1 conv of the 56^2 stage as one streaming pass (forward): z1[p][m] = sum_c x[p][c] W1[m][c] + the per-channel
+// sum / sum of squares of the bf16-rounded z1.  K = cin <= 32 is ONE MFMA step: the product is a pure output stream (mid / cin = 6
+// bytes written per byte read).  W1 stays in LDS; the strip's output tile is assembled in an LDS image and leaves as whole 16-byte
+// row chunks by threads that each own one channel octet for the block's lifetime -- the same threads keep that octet's statistics
+// in registers, so no second pass and no atomics (slab + mmsim_launch_reduce at the end).
+struct PwExp {
+  const bf16* x; const bf16* w1; bf16* z1; float* parts;
+  int P, mid, cin, nstrips, per_block;
+};
+
+template <int BM, int CIN_T>
+__global__ __launch_bounds__(256) void pw_expand_fwd_kernel(PwExp p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XP = CIN_T * 32 + 16;                     // x / W1 image pitch (bytes)
+  constexpr int KS = CIN_T / 2;                           // 32-deep reduction steps
+  constexpr int MT_W = BM / 64;                           // pixel tiles per wave
+  static_assert(MT_W >= 1 && (CIN_T % 2) == 0, "tile split");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = p.mid >> 3, XG = p.cin >> 3, NT = (p.mid + 15) >> 4;
+  const int OP = NT * 32 + 16;                            // output image pitch (bytes)
+  char* ximg = smem;                                      // [BM][CIN_T*16]
+  char* wimg = ximg + BM * XP;                            // [NT*16][CIN_T*16]  W1 (rows = mid, zero rows past mid)
+  char* oimg = wimg + NT * 16 * XP;                       // [BM][NT*16]
+  for (int i = tid; i < (BM * XP + NT * 16 * XP) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  for (int i = tid; i < p.mid * XG; i += 256) {
+    const int r = i / XG, c = i - r * XG;
+    *reinterpret_cast<uint4*>(wimg + r * XP + c * 16) = *reinterpret_cast<const uint4*>(p.w1 + (size_t)r * p.cin + c * 8);
+  }
+  // copy-out ownership: thread -> (channel octet un, pixel lane pl); NR pixel rows per pass
+  const int NR = 256 / G;
+  const int un = tid % G, pl = tid / G;
+  const bool owner = pl < NR;
+  float st[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) st[e] = 0.f;
+  const int nxch = BM * XG;
+  uint4 vx;
+  auto request = [&](int strip) {
+    vx = *reinterpret_cast<const uint4*>(p.x + (size_t)strip * BM * p.cin + (size_t)min(tid, nxch - 1) * 8);
+  };
+  static_assert(BM * 4 <= 256, "one x chunk per thread (cin <= 32)");
+  const int sbeg = blockIdx.x * p.per_block, send = min(p.nstrips, sbeg + p.per_block);
+  if (sbeg < send) request(sbeg);
+  for (int strip = sbeg; strip < send; ++strip) {
+    __syncthreads();                     // A: the previous strip's output image has been copied out
+    if (tid < nxch) {
+      const int pix = tid / XG, u = tid - pix * XG;
+      *reinterpret_cast<uint4*>(ximg + pix * XP + u * 16) = vx;
+    }
+    __syncthreads();                     // B
+    if (strip + 1 < send) request(strip + 1);
+#pragma unroll
+    for (int m = 0; m < MT_W; ++m) {
+      const int mt = wave * MT_W + m;
+      bf8 xf[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        xf[ks] = *reinterpret_cast<const bf8*>(ximg + (mt * 16 + (lane & 15)) * XP + (ks * 4 + (lane >> 4)) * 16);
+      for (int nt = 0; nt < NT; ++nt) {
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf8 wf = *reinterpret_cast<const bf8*>(wimg + (nt * 16 + (lane & 15)) * XP + (ks * 4 + (lane >> 4)) * 16);
+          acc = mfma16(wf, xf[ks], acc);                   // acc[e] = z1[pixel lane&15][channel nt*16 + 4(lane>>4) + e]
+        }
+        const bf4 o = {f2bf(acc[0]), f2bf(acc[1]), f2bf(acc[2]), f2bf(acc[3])};
+        *reinterpret_cast<bf4*>(oimg + (mt * 16 + (lane & 15)) * OP + (nt * 16 + (lane >> 4) * 4) * 2) = o;
+      }
+    }
+    __syncthreads();                     // C: the output image is complete
+    if (owner) {
+      bf16* dst = p.z1 + (size_t)strip * BM * p.mid + un * 8;
+      for (int pix = pl; pix < BM; pix += NR) {
+        const uint4 v = *reinterpret_cast<const uint4*>(oimg + pix * OP + un * 16);
+        *reinterpret_cast<uint4*>(dst + (size_t)pix * p.mid) = v;
+        float f[8];
+        unpackN<8>(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { st[e] += f[e]; st[8 + e] += f[e] * f[e]; }
+      }
+    }
+  }
+  // ---- statistics: sum the pixel lanes through LDS (the images are free), one slab row [2][mid] per block
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);            // [NR][16][G]
+  if (owner) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(pl * 16 + e) * G + un] = st[e];
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * p.mid; i += 256) {
+    const int which = i >= p.mid, c = i - which * p.mid;
+    const int e = which * 8 + (c & 7), u = c >> 3;
+    float t = 0.f;
+    for (int r = 0; r < NR; ++r) t += red[(r * 16 + e) * G + u];
+    p.parts[(size_t)blockIdx.x * 2 * p.mid + i] = t;
+  }
+}
+
+extern "C" int mmsim_pw_expand_fwd_eligible(int P, int mid, int cin) {
+  return P > 0 && (P % 64) == 0 && (mid % 8) == 0 && (cin % 8) == 0 && cin <= 32 && mid <= 192 && mid >= 64;
+}
+
+extern "C" int mmsim_pw_expand_fwd(const void* x, const void* w1_bf16, void* z1, float* sums, int P, int mid, int cin, float* scratch,
+                                   unsigned long long scratch_floats, void* stream) {
+  MMSIM_REQUIRE(x && w1_bf16 && z1 && sums && scratch, "pw_expand_fwd: null operand");
+  MMSIM_REQUIRE(mmsim_pw_expand_fwd_eligible(P, mid, cin), "pw_expand_fwd: shape not eligible (see mmsim_pw_expand_fwd_eligible)");
+  constexpr int BM = 64, CIN_T = 2;
+  PwExp p;
+  p.x = (const bf16*)x; p.w1 = (const bf16*)w1_bf16; p.z1 = (bf16*)z1; p.P = P; p.mid = mid; p.cin = cin;
+  p.nstrips = P / BM;
+  const int NT = (mid + 15) / 16, XP = CIN_T * 32 + 16, OP = NT * 32 + 16, G = mid / 8, NR = 256 / G;
+  size_t lds = (size_t)BM * XP + (size_t)NT * 16 * XP + (size_t)BM * OP;
+  const size_t red = (size_t)NR * 16 * G * 4;
+  if (red > lds) lds = red;
+  MMSIM_REQUIRE(lds <= 64 * 1024, "pw_expand_fwd: LDS images too large");
+  int grid = p.nstrips < 1024 ? p.nstrips : 1024;
+  while (grid > 64 && (size_t)grid * 2 * mid > scratch_floats) grid /= 2;
+  MMSIM_REQUIRE((size_t)grid * 2 * mid <= scratch_floats, "pw_expand_fwd: scratch too small");
+  p.per_block = (p.nstrips + grid - 1) / grid;
+  grid = (p.nstrips + p.per_block - 1) / p.per_block;
+  p.parts = scratch;
+  hipLaunchKernelGGL((pw_expand_fwd_kernel<BM, CIN_T>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+  mmsim_launch_reduce(scratch, grid, 2 * mid, sums, 1, (hipStream_t)stream);      /* sums += (pre-zeroed by the caller) */
+  return mmsim_check_launch("pw_expand_fwd");
+}
+
 // Backward of the same conv as one streaming pass over a2:
 //   d(a2 * gate)[p][c] = sum_co dz3[p][co] W3[co][c]        (bf16 out, consumed by mmsim_pool_bn_bwd / mmsim_dwtile_bwd)
 //   dW3[co][c]        += sum_p  dz3[p][co] (a2[p][c] * gate[p / HW][c])

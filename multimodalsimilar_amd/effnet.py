@@ -308,8 +308,11 @@ class EfficientNet(nn.Module):
             bs.z1 = E(P_in, b.mid)
             sm = self._sums(st, n + "." + e_bn, "f")
             w1 = SV(n + ".conv_pw.weight", (b.mid, b.cin))
-            lib.gemm_bf16_bnstats(0, P_in, b.mid, b.cin, cur.data_ptr(), b.cin, w1.data_ptr(), b.cin, bs.z1.data_ptr(), b.mid,
-                                  None, None, None, 1, sm.data_ptr(), *self._scr(), s)     # conv + the BN statistics of z1
+            if _PW_PROJECT and lib.pw_expand_fwd_eligible(P_in, b.mid, b.cin):
+                lib.pw_expand_fwd(cur.data_ptr(), w1.data_ptr(), bs.z1.data_ptr(), sm.data_ptr(), P_in, b.mid, b.cin, *self._scr(), s)
+            else:
+                lib.gemm_bf16_bnstats(0, P_in, b.mid, b.cin, cur.data_ptr(), b.cin, w1.data_ptr(), b.cin, bs.z1.data_ptr(), b.mid,
+                                      None, None, None, 1, sm.data_ptr(), *self._scr(), s)     # conv + the BN statistics of z1
             self._bn_finalize(st, n + "." + e_bn, sm, P_in)
             if _DWTILE and b.stride == 1:
                 bs.a1 = None          # a1 = silu(bn(z1)) is formed inside the depthwise kernels, never materialised

@@ -614,3 +614,25 @@ def test_streaming_projection_backward_equals_the_gemm_form(B, HW, mid, cout):
     ops.gemm(dz3, w3, da_g, b_kmajor=False)
     assert relerr(da, da_g) < 4e-3 and relerr(dw - base, dw_g - base) < 2e-3
     assert not lib.pw_project_bwd_eligible(P, HW, 336, 56)
+
+
+@pytest.mark.parametrize("P,mid,cin", [(640, 192, 32), (1024, 144, 24), (64, 64, 8), (4096, 176, 16)])
+def test_streaming_expansion_forward_equals_the_gemm_form(P, mid, cin):
+    """mmsim_pw_expand_fwd (56^2-stage expansion conv as an output stream: W1 in LDS, output tile assembled in LDS, statistics kept by
+    the threads that copy it out) against fp32 torch and mmsim_gemm_bf16_bnstats."""
+    lib, s = _lib()
+    assert lib.pw_expand_fwd_eligible(P, mid, cin)
+    x = rnd(P, cin, seed=1).bfloat16()
+    w1 = rnd(mid, cin, seed=2, scale=0.3).bfloat16()
+    z1 = torch.empty(P, mid, dtype=torch.bfloat16, device=DEV)
+    sums = torch.zeros(2 * mid, device=DEV)
+    lib.pw_expand_fwd(x.data_ptr(), w1.data_ptr(), z1.data_ptr(), sums.data_ptr(), P, mid, cin, *scr(), s)
+    assert relerr(z1, x.float() @ w1.float().t()) < 1e-2
+    assert relerr(sums[:mid], z1.float().sum(0)) < 1e-4 and relerr(sums[mid:], (z1.float() ** 2).sum(0)) < 1e-4
+    z1g = torch.empty_like(z1)
+    sums_g = torch.zeros_like(sums)
+    lib.gemm_bf16_bnstats(0, P, mid, cin, x.data_ptr(), cin, w1.data_ptr(), cin, z1g.data_ptr(), mid, None, None, None, 1,
+                          sums_g.data_ptr(), *scr(), s)
+    assert torch.equal(z1, z1g) or relerr(z1, z1g) < 4e-3                 # one 32-deep MFMA step either way: usually bit-equal
+    assert relerr(sums, sums_g) < 1e-3
+    assert not lib.pw_expand_fwd_eligible(P, 336, 56) and not lib.pw_expand_fwd_eligible(P + 8, mid, cin)

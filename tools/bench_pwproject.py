@@ -39,3 +39,12 @@ for name, hw, mid, cout in (("ds0 112^2", 12544, 48, 24), ("ds1 112^2", 12544, 2
         byb = (2 * P * mid + 2 * P * cout) * 2
         line += f" || bwd streaming {tb:6.0f} us {byb/tb/1e6:5.2f} TB/s | gemm pair {tp:6.0f} us {byb/tp/1e6:5.2f} TB/s"
     print(line, flush=True)
+for name, hw, cin, mid in (("1.0 112^2 expand", 12544, 24, 144), ("1.x 56^2 expand", 3136, 32, 192)):
+    P = B * hw
+    x = torch.randn(P, cin, device="cuda").to(bf); w1 = torch.randn(mid, cin, device="cuda").to(bf)
+    z1 = torch.empty(P, mid, dtype=bf, device="cuda"); sums = torch.zeros(2 * mid, device="cuda")
+    tn = t(lambda: lib.pw_expand_fwd(x.data_ptr(), w1.data_ptr(), z1.data_ptr(), sums.data_ptr(), P, mid, cin, scr.data_ptr(), scr.numel(), s))
+    tg = t(lambda: lib.gemm_bf16_bnstats(0, P, mid, cin, x.data_ptr(), cin, w1.data_ptr(), cin, z1.data_ptr(), mid, None, None, None, 1,
+                                         sums.data_ptr(), scr.data_ptr(), scr.numel(), s))
+    by = (P * mid + P * cin) * 2
+    print(f"{name:18s} cin={cin} mid={mid}: streaming {tn:6.0f} us {by/tn/1e6:5.2f} TB/s | gemm {tg:6.0f} us {by/tg/1e6:5.2f} TB/s", flush=True)
