@@ -658,10 +658,10 @@ __device__ __forceinline__ f4 mfma16(bf8 first, bf8 second, f4 acc) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(first, second, acc, 0, 0, 0);      // acc[e] = C[second row lane&15][first row 4(lane>>4)+e]
 }
 
-template <int BM, int CIN_T, int MAXW>
-__global__ __launch_bounds__(256) void pw_expand_bwd_kernel(PwBwd p) {
+template <int BM, int CIN_T, int MAXW, int NTHR = 256, int NCH = 6>
+__global__ __launch_bounds__(NTHR) void pw_expand_bwd_kernel(PwBwd p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NCH = 6;                                  // 16-byte chunks per thread and tensor of one strip (host checks)
+  constexpr int NW = NTHR / 64;                           // waves per block; NCH: 16-byte chunks per thread and tensor of one strip (host checks)
   constexpr int XP = CIN_T * 32 + 16;                     // X / W1 image pitch (bytes)
   constexpr int MTD = BM / 16;                            // pixel tiles of the dgrad product
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -672,13 +672,13 @@ __global__ __launch_bounds__(256) void pw_expand_bwd_kernel(PwBwd p) {
   char* wimg = ximg + BM * XP;                            // [KS*32][CIN_T*16] bf16: W1 (rows = mid)
   float* cst = reinterpret_cast<float*>(wimg + p.KS * 32 * XP);      // [3][mid]: scale, A, Bc
   // ---- one-time staging: zero the images (pads must be zero), W1, the folded BatchNorm-backward constants
-  for (int i = tid; i < (BM * ZP + BM * XP + p.KS * 32 * XP) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < (BM * ZP + BM * XP + p.KS * 32 * XP) / 16; i += NTHR) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
-  for (int i = tid; i < p.mid * (p.cin >> 3); i += 256) {
+  for (int i = tid; i < p.mid * (p.cin >> 3); i += NTHR) {
     const int r = i / (p.cin >> 3), c = i - r * (p.cin >> 3);
     *reinterpret_cast<uint4*>(wimg + r * XP + c * 16) = *reinterpret_cast<const uint4*>(p.w1 + (size_t)r * p.cin + c * 8);
   }
-  for (int c = tid; c < p.mid; c += 256) {
+  for (int c = tid; c < p.mid; c += NTHR) {
     const float sc = p.sc1[c], bc = sc * p.rs1[c] * p.sums1[p.mid + c] * p.invP;
     cst[c] = sc; cst[p.mid + c] = sc * p.sums1[c] * p.invP - p.mu1[c] * bc; cst[2 * p.mid + c] = bc;
     if (blockIdx.x == 0) { p.dgamma[c] += p.sums1[p.mid + c]; p.dbeta[c] += p.sums1[c]; }
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256) void pw_expand_bwd_kernel(PwBwd p) {
     const size_t base = (size_t)strip * BM * p.mid;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int q = min(tid + 256 * i, nchunks - 1);
+      const int q = min(tid + NTHR * i, nchunks - 1);
       vd[i] = *reinterpret_cast<const uint4*>(p.dpre + base + (size_t)q * 8);
       vz[i] = *reinterpret_cast<const uint4*>(p.z1 + base + (size_t)q * 8);
     }
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void pw_expand_bwd_kernel(PwBwd p) {
     // ---- dz1 -> Z image, x -> X image
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int q = tid + 256 * i;
+      const int q = tid + NTHR * i;
       if (q < nchunks) {
         const int pix = q / G, un = q - pix * G;
         const bf8 d = __builtin_bit_cast(bf8, vd[i]), z = __builtin_bit_cast(bf8, vz[i]);
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256) void pw_expand_bwd_kernel(PwBwd p) {
     }
     {
       const int xg = p.cin >> 3;
-      for (int q = tid; q < BM * xg; q += 256) {
+      for (int q = tid; q < BM * xg; q += NTHR) {
         const int pix = q / xg, un = q - pix * xg;
         *reinterpret_cast<uint4*>(ximg + pix * XP + un * 16) =
             *reinterpret_cast<const uint4*>(p.x + ((size_t)strip * BM + pix) * p.cin + un * 8);
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(256) void pw_expand_bwd_kernel(PwBwd p) {
     __syncthreads();
     if (strip + (int)gridDim.x < p.nstrips) request(strip + gridDim.x);      // the next strip's loads fly under the MFMAs
     // ---- dx = dz1 W1: (BM/16) x CIN_T tiles over the waves
-    for (int t = wave; t < MTD * CIN_T; t += 4) {
+    for (int t = wave; t < MTD * CIN_T; t += NW) {
       const int mt = t / CIN_T, nt = t - mt * CIN_T;
       f4 acc = {0.f, 0.f, 0.f, 0.f};
       for (int ks = 0; ks < p.KS; ++ks) {
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(256) void pw_expand_bwd_kernel(PwBwd p) {
     // ---- dW1 += dz1^T x: tiles (mid/16) x CIN_T, reduction over the strip's pixels
 #pragma unroll
     for (int i = 0; i < MAXW; ++i) {
-      const int t = wave + 4 * i;
+      const int t = wave + NW * i;
       if (t < nwt) {                     // wave-uniform: EXEC stays all ones for the transposing reads
         const int mt = t / CIN_T, nt = t - mt * CIN_T;
 #pragma unroll
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(256) void pw_expand_bwd_kernel(PwBwd p) {
   float* slab = p.parts + (size_t)blockIdx.x * p.mid * p.cin;
 #pragma unroll
   for (int i = 0; i < MAXW; ++i) {
-    const int t = wave + 4 * i;
+    const int t = wave + NW * i;
     if (t < nwt) {
       const int mt = t / CIN_T, nt = t - mt * CIN_T;
       const int cm = mt * 16 + (lane & 15), ci = nt * 16 + (lane >> 4) * 4;
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(256) void pw_expand_bwd_kernel(PwBwd p) {
   }
 }
 
-template <int BM, int CIN_T, int MAXW>
+template <int BM, int CIN_T, int MAXW, int NTHR = 256, int NCH = 6>
 static int launch_pw_expand_bwd(PwBwd p, float* dw1, hipStream_t s, float* scratch, unsigned long long scratch_floats) {
   p.nstrips = p.P / BM;
   p.KS = (p.mid + 31) / 32;
@@ -785,17 +785,17 @@ static int launch_pw_expand_bwd(PwBwd p, float* dw1, hipStream_t s, float* scrat
   const size_t slab = (size_t)p.mid * p.cin;
   while (grid > 64 && (size_t)grid * slab > scratch_floats) grid /= 2;
   MMSIM_REQUIRE((size_t)grid * slab <= scratch_floats, "pw_expand_bwd: scratch too small");
-  MMSIM_REQUIRE(BM * (p.mid >> 3) <= 256 * 6, "pw_expand_bwd: strip too wide for the staging registers");
-  MMSIM_REQUIRE(((p.mid + 15) / 16) * CIN_T <= 4 * MAXW, "pw_expand_bwd: weight gradient does not fit the accumulators");
+  MMSIM_REQUIRE(BM * (p.mid >> 3) <= NTHR * NCH, "pw_expand_bwd: strip too wide for the staging registers");
+  MMSIM_REQUIRE(((p.mid + 15) / 16) * CIN_T <= (NTHR / 64) * MAXW, "pw_expand_bwd: weight gradient does not fit the accumulators");
   static unsigned long long done = 0;
   const int dev = mmsim_current_device();
   if (!((done >> dev) & 1)) {
-    (void)hipFuncSetAttribute((const void*)pw_expand_bwd_kernel<BM, CIN_T, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)pw_expand_bwd_kernel<BM, CIN_T, MAXW, NTHR, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     done |= 1ull << dev;
   }
-  MMSIM_REQUIRE(lds <= 96 * 1024, "pw_expand_bwd: LDS images too large");
+  MMSIM_REQUIRE(lds <= 120 * 1024, "pw_expand_bwd: LDS images too large");
   p.parts = scratch;
-  hipLaunchKernelGGL((pw_expand_bwd_kernel<BM, CIN_T, MAXW>), dim3(grid), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((pw_expand_bwd_kernel<BM, CIN_T, MAXW, NTHR, NCH>), dim3(grid), dim3(NTHR), lds, s, p);
   mmsim_launch_reduce(scratch, grid, (int)slab, dw1, 1, s);
   return mmsim_check_launch("pw_expand_bwd");
 }
@@ -1310,5 +1310,6 @@ extern "C" int mmsim_pw_expand_bwd(const void* dpre, const void* z1, const void*
   p.sc1 = scale1; p.mu1 = mean1; p.rs1 = rstd1; p.sums1 = sums1; p.dx = (bf16*)dx; p.dgamma = dgamma1; p.dbeta = dbeta1;
   p.P = P; p.mid = mid; p.cin = cin; p.invP = 1.0f / (float)P;
   if (cin <= 32 && mid <= 192) return launch_pw_expand_bwd<64, 2, 6>(p, dw1, (hipStream_t)stream, scratch, scratch_floats);
-  return launch_pw_expand_bwd<32, 4, 22>(p, dw1, (hipStream_t)stream, scratch, scratch_floats);
+  // the 28^2 stage (mid = 336): one 8-wave block per CU over 64-pixel strips (110 KiB of images) -- the 4-wave / 32-pixel form ran at 1.4 TB/s
+  return launch_pw_expand_bwd<64, 4, 11, 512, 6>(p, dw1, (hipStream_t)stream, scratch, scratch_floats);
 }
