@@ -247,6 +247,10 @@ int mmsim_dwconv_bwd_data(const void* dz, const float* w_tap_major, const void* 
                           void* stream);
 int mmsim_dwconv_bwd_weight(const void* dz, const void* a, float* g_tap_major, int B, int Hi, int Wi, int C, int K, int S,
                             float* scratch, unsigned long long scratch_floats, void* stream);
+/* The same with the operand formed on the fly: a = silu(xf_scale * z + xf_shift) (rounded to bf16 as a stored copy would be), z the
+ * pre-BatchNorm tensor -- the stride-2 MBConv blocks then never store the activated expansion. */
+int mmsim_dwconv_bwd_weight_xf(const void* dz, const void* z, const float* xf_scale, const float* xf_shift, float* g_tap_major, int B,
+                               int Hi, int Wi, int C, int K, int S, float* scratch, unsigned long long scratch_floats, void* stream);
 /* ---- LDS-tiled depthwise kernels (csrc/mbconv.hip): the timm MBConv depthwise stage under cv_classifier.py:49 with the
  * passes either side of it folded in.  All activations NHWC bf16, w_tap_major [K*K][C] fp32 (mmsim_dw_weight_to_tap_major),
  * scratch >= the per-block partial slabs (checked), sums pre-zeroed by the caller as for every BN-sum producer.

@@ -836,7 +836,8 @@ __global__ __launch_bounds__(256) DW_OCC void dwconv_bwd_data_kernel(const bf16*
 // backward weight (tap-major gT [K*K][C]): one kernel row kh per blockIdx.z; thread = (octet, output row lane)
 template <int K, int S>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16* __restrict__ dz, const bf16* __restrict__ a, float* parts, DwGeom g,
-                                                                int rows_per_block) {
+                                                                int rows_per_block, const float* __restrict__ xf_scale,
+                                                                const float* __restrict__ xf_shift) {
   constexpr int PAD = K / 2;
   __shared__ float lds[256 * 8 * K];
   const CgMap m = cg_map(g.C);
@@ -848,6 +849,10 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16* __re
     const int c0 = m.cg * 8;
     const int nrows = g.B * g.Ho;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
+    // xf_scale given: `a` is the pre-BatchNorm tensor and the operand silu(scale a + shift) is formed here (stride-2 blocks: the
+    // activated tensor is then never stored)
+    float sc[8], sh[8];
+    if (xf_scale) { ld8f(xf_scale + c0, sc); ld8f(xf_shift + c0, sh); }
     for (int r = r0 + m.rl; r < r1; r += m.nr) {
       const int ho = r % g.Ho, b = r / g.Ho;
       const int hi = ho * S - PAD + kh;
@@ -868,6 +873,15 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16* __re
         float xin[NIN][8];
 #pragma unroll
         for (int x = 0; x < NIN; ++x) unpack8(ar[x], xin[x]);
+        if (xf_scale) {
+#pragma unroll
+          for (int x = 0; x < NIN; ++x) {
+            const int wi = w0 * S - PAD + x;
+            const float ok = (wi >= 0 && wi < g.Wi) ? 1.f : 0.f;          // the zero padding is of the ACTIVATED tensor
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xin[x][e] = bf2f(f2bf(silu_f(xin[x][e] * sc[e] + sh[e]))) * ok;      // rounded as the stored a1 was
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float d[8];
@@ -1347,15 +1361,27 @@ extern "C" int mmsim_dwconv_bwd_data(const void* dz, const float* w_tap_major, c
   return mmsim_check_launch("dwconv_bwd_data");
 }
 
+static int dwconv_bwd_weight_impl(const void* dz, const void* a, const float* xf_scale, const float* xf_shift, float* g_tap_major, int B,
+                                  int Hi, int Wi, int C, int K, int S, float* scratch, unsigned long long scratch_floats, void* stream);
 extern "C" int mmsim_dwconv_bwd_weight(const void* dz, const void* a, float* g_tap_major, int B, int Hi, int Wi, int C, int K, int S,
                                        float* scratch, unsigned long long scratch_floats, void* stream) {
+  return dwconv_bwd_weight_impl(dz, a, nullptr, nullptr, g_tap_major, B, Hi, Wi, C, K, S, scratch, scratch_floats, stream);
+}
+extern "C" int mmsim_dwconv_bwd_weight_xf(const void* dz, const void* z, const float* xf_scale, const float* xf_shift, float* g_tap_major,
+                                          int B, int Hi, int Wi, int C, int K, int S, float* scratch, unsigned long long scratch_floats,
+                                          void* stream) {
+  MMSIM_REQUIRE(xf_scale && xf_shift, "dwconv_bwd_weight_xf: scale and shift required");
+  return dwconv_bwd_weight_impl(dz, z, xf_scale, xf_shift, g_tap_major, B, Hi, Wi, C, K, S, scratch, scratch_floats, stream);
+}
+static int dwconv_bwd_weight_impl(const void* dz, const void* a, const float* xf_scale, const float* xf_shift, float* g_tap_major, int B,
+                                  int Hi, int Wi, int C, int K, int S, float* scratch, unsigned long long scratch_floats, void* stream) {
   DwGeom g; int rc = dw_check(B, Hi, Wi, C, K, S, &g); if (rc) return rc;
   MMSIM_REQUIRE(dz && a && g_tap_major, "dwconv_bwd_weight: null operand");
   const int nrows = B * g.Ho;
   int rpb = (nrows + 127) / 128; const int nr = nr_of(C); if (rpb < nr) rpb = nr;
   dim3 grid((nrows + rpb - 1) / rpb, cg_grid_y(C), K);
   REQ_SCRATCH((size_t)grid.x * K * K * C, "dwconv_bwd_weight");
-  DW_DISPATCH(dwconv_bwd_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, (const bf16*)a, scratch, g, rpb)
+  DW_DISPATCH(dwconv_bwd_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, (const bf16*)a, scratch, g, rpb, xf_scale, xf_shift)
   launch_reduce(scratch, grid.x, K * K * C, g_tap_major, 1, (hipStream_t)stream);      /* g_tap_major += */
   return mmsim_check_launch("dwconv_bwd_weight");
 }

@@ -76,6 +76,8 @@ _DWTILE = os.environ.get("MMSIM_DWTILE", "1") != "0"
 _PW_FUSED = os.environ.get("MMSIM_PW_FUSED", "1") != "0"
 # MMSIM_PW_PROJECT=0: projection conv of the early stages through the generic GEMM instead of the streaming kernels (A/B switch)
 _PW_PROJECT = os.environ.get("MMSIM_PW_PROJECT", "1") != "0"
+# MMSIM_S2_XF=0: stride-2 blocks store a1 = silu(bn1(z1)) (a bn_apply pass) instead of re-forming it in the depthwise kernels
+_S2_XF = os.environ.get("MMSIM_S2_XF", "1") != "0"
 
 class _Holder(nn.Module):
     pass
@@ -314,7 +316,7 @@ class EfficientNet(nn.Module):
                 lib.gemm_bf16_bnstats(0, P_in, b.mid, b.cin, cur.data_ptr(), b.cin, w1.data_ptr(), b.cin, bs.z1.data_ptr(), b.mid,
                                       None, None, None, 1, sm.data_ptr(), *self._scr(), s)     # conv + the BN statistics of z1
             self._bn_finalize(st, n + "." + e_bn, sm, P_in)
-            if _DWTILE and b.stride == 1:
+            if _DWTILE and (b.stride == 1 or _S2_XF):
                 bs.a1 = None          # a1 = silu(bn(z1)) is formed inside the depthwise kernels, never materialised
             else:
                 bs.a1 = E(P_in, b.mid)
@@ -514,7 +516,12 @@ class EfficientNet(nn.Module):
             self._bn_bwd(st, n + "." + d_bn, da2g, bs.z2, P_out, b.mid, dz2, act=True, gate=bs.gate, dsq=ds, hw=Ho * Wo,
                          sums_ready=True)
             del da2g
-            lib.dwconv_bwd_weight(dz2.data_ptr(), bs.a1.data_ptr(), gT.data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride, *self._scr(), s)
+            if bs.a1 is None:      # stride-2 block without a stored a1: the weight gradient re-forms it from z1
+                en1 = n + "." + e_bn
+                lib.dwconv_bwd_weight_xf(dz2.data_ptr(), bs.z1.data_ptr(), self._bnp(st, en1, 2).data_ptr(), self._bnp(st, en1, 3).data_ptr(),
+                                         gT.data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride, *self._scr(), s)
+            else:
+                lib.dwconv_bwd_weight(dz2.data_ptr(), bs.a1.data_ptr(), gT.data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride, *self._scr(), s)
         lib.dw_grad_from_tap_major(gT.data_ptr(), G(n + ".conv_dw.weight").data_ptr(), b.mid, b.k, s)
         if b.type == "ir":
             en = n + "." + e_bn

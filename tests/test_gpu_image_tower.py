@@ -91,6 +91,13 @@ def test_depthwise_conv_fwd_bwd(K, S, H, C):
     g = torch.ones(C, 1, K, K, device=DEV)
     lib.dw_grad_from_tap_major(gT.data_ptr(), g.data_ptr(), C, K, s)
     assert relerr(g - 1, wr.grad) < 1e-2
+    # the same gradient with the operand re-formed from the pre-BatchNorm tensor (stride-2 blocks store no a1): a = silu(sc z + sh)
+    a_from = (F.silu(z1.float() * scale + shift)).bfloat16()
+    gT_a = torch.zeros(K * K, C, device=DEV)
+    lib.dwconv_bwd_weight(dzb.data_ptr(), a_from.data_ptr(), gT_a.data_ptr(), B, H, W, C, K, S, *scr(), s)
+    gT_x = torch.zeros(K * K, C, device=DEV)
+    lib.dwconv_bwd_weight_xf(dzb.data_ptr(), z1.data_ptr(), scale.data_ptr(), shift.data_ptr(), gT_x.data_ptr(), B, H, W, C, K, S, *scr(), s)
+    assert relerr(gT_x, gT_a) < 2e-3
 
 
 @pytest.mark.parametrize("K,S,H,C,xf", [(3, 1, 12, 48, True), (5, 1, 10, 40, True), (3, 2, 16, 144, False), (5, 2, 14, 192, False),
