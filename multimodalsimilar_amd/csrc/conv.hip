@@ -489,12 +489,19 @@ struct BnBwd {
   const float* gate; const float* dsq; int hw; int act; int P; int C; float inv_hw; FastDiv d_hw;
 };
 // da = (gate ? dy*g + dsq/HW : dy) * (act ? silu'(scale*z+shift) : 1)
-__device__ __forceinline__ void bn_bwd_elem(const BnBwd& p, int r, int c0, float (&da)[8], float (&zh)[8]) {
-  const size_t off = (size_t)r * p.C + c0;
-  float d[8], z[8], mu[8], rs[8];
-  unpack8(*reinterpret_cast<const uint4*>(p.dy + off), d);
-  unpack8(*reinterpret_cast<const uint4*>(p.z + off), z);
-  ld8f(p.mean + c0, mu); ld8f(p.rstd + c0, rs);
+// The per-channel vectors are loaded ONCE per thread (BnBwdCh) and the row loops below request FOUR rows' dy | z chunks before
+// the first use: with one row per trip (load, wait, compute, store) a block's 30-40 trips ran one L2 round trip after the other
+// and a 7-MB tensor took as long as a 70-MB one (37 us per launch whatever the size).
+struct BnBwdCh { float mu[8], rs[8], sc[8], sh[8]; };
+__device__ __forceinline__ void bn_bwd_ch(const BnBwd& p, int c0, BnBwdCh& ch) {
+  ld8f(p.mean + c0, ch.mu); ld8f(p.rstd + c0, ch.rs);
+  if (p.act) { ld8f(p.scale + c0, ch.sc); ld8f(p.shift + c0, ch.sh); }
+}
+__device__ __forceinline__ void bn_bwd_elem(const BnBwd& p, const BnBwdCh& ch, int r, int c0, const uint4& dv, const uint4& zv,
+                                            float (&da)[8], float (&zh)[8]) {
+  float d[8], z[8];
+  unpack8(dv, d);
+  unpack8(zv, z);
   if (p.gate) {
     const int b = (int)fdiv((unsigned int)r, p.d_hw);
     float g[8], q[8];
@@ -503,13 +510,11 @@ __device__ __forceinline__ void bn_bwd_elem(const BnBwd& p, int r, int c0, float
     for (int e = 0; e < 8; ++e) d[e] = d[e] * g[e] + q[e] * p.inv_hw;
   }
   if (p.act) {
-    float sc[8], sh[8];
-    ld8f(p.scale + c0, sc); ld8f(p.shift + c0, sh);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) d[e] *= silu_grad_f(z[e] * sc[e] + sh[e]);
+    for (int e = 0; e < 8; ++e) d[e] *= silu_grad_f(z[e] * ch.sc[e] + ch.sh[e]);
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { da[e] = d[e]; zh[e] = (z[e] - mu[e]) * rs[e]; }
+  for (int e = 0; e < 8; ++e) { da[e] = d[e]; zh[e] = (z[e] - ch.mu[e]) * ch.rs[e]; }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwd p, float* parts, int rows_per_block) {
@@ -519,12 +524,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwd p, float* part
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   if (m.active) {
+    const int c0 = m.cg * 8;
+    BnBwdCh ch;
+    bn_bwd_ch(p, c0, ch);
     const int r0 = blockIdx.x * rows_per_block, r1 = min(p.P, r0 + rows_per_block);
-    for (int r = r0 + m.rl; r < r1; r += m.nr) {
-      float da[8], zh[8];
-      bn_bwd_elem(p, r, m.cg * 8, da, zh);
+    for (int r = r0 + m.rl; r < r1; r += 4 * m.nr) {
+      uint4 dv[4], zv[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { acc[e] += da[e]; acc[8 + e] += da[e] * zh[e]; }
+      for (int q = 0; q < 4; ++q) {
+        const size_t off = (size_t)min(r + q * m.nr, r1 - 1) * p.C + c0;
+        dv[q] = *reinterpret_cast<const uint4*>(p.dy + off);
+        zv[q] = *reinterpret_cast<const uint4*>(p.z + off);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rq = r + q * m.nr;
+        const float ok = rq < r1 ? 1.f : 0.f;
+        float da[8], zh[8];
+        bn_bwd_elem(p, ch, min(rq, r1 - 1), c0, dv[q], zv[q], da, zh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float v = da[e] * ok; acc[e] += v; acc[8 + e] += v * zh[e]; }
+      }
     }
   }
   block_reduce_store<16>(acc, m, lds, parts + (size_t)blockIdx.x * 2 * p.C, (size_t)p.C);
@@ -541,14 +561,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwd p, const float*
   const int c0 = m.cg * 8;
   float s1[8], s2[8], sc[8];
   ld8f(sums + c0, s1); ld8f(sums + p.C + c0, s2); ld8f(p.scale + c0, sc);
+  BnBwdCh ch;
+  bn_bwd_ch(p, c0, ch);
   const float invP = 1.0f / (float)p.P;
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(p.P, r0 + rows_per_block);
-  for (int r = r0 + m.rl; r < r1; r += m.nr) {
-    float da[8], zh[8], o[8];
-    bn_bwd_elem(p, r, c0, da, zh);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = sc[e] * (da[e] - s1[e] * invP - zh[e] * s2[e] * invP);
-    *reinterpret_cast<uint4*>(dz + (size_t)r * p.C + c0) = pack8(o);
+  for (int e = 0; e < 8; ++e) { s1[e] *= invP; s2[e] *= invP; }
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(p.P, r0 + rows_per_block);
+  for (int r = r0 + m.rl; r < r1; r += 4 * m.nr) {
+    uint4 dv[4], zv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const size_t off = (size_t)min(r + q * m.nr, r1 - 1) * p.C + c0;
+      dv[q] = *reinterpret_cast<const uint4*>(p.dy + off);
+      zv[q] = *reinterpret_cast<const uint4*>(p.z + off);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rq = r + q * m.nr;
+      if (rq < r1) {
+        float da[8], zh[8], o[8];
+        bn_bwd_elem(p, ch, rq, c0, dv[q], zv[q], da, zh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = sc[e] * (da[e] - s1[e] - zh[e] * s2[e]);
+        *reinterpret_cast<uint4*>(dz + (size_t)rq * p.C + c0) = pack8(o);
+      }
+    }
   }
 }
 
