@@ -21,9 +21,15 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned seed) {
       } else if (MODE == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[i]) : "v"((f2){x, y}), "v"((f2){y, x}));
-      } else {
+      } else if (MODE == 2) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(a[i]) : "v"(ux), "v"(uy));
+      } else if (MODE == 3) {        // f16 (high half of a packed word) x f32 + f32: no unpack instruction
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(ux), "v"(y));
+      } else {                       // the unpack pair the bf16 tiles need today: v_lshlrev_b32 / v_and_b32
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(a[i]) : "v"(ux + i));
       }
     }
   }
@@ -47,4 +53,4 @@ template <int MODE> static void run(const char* name, int per_iter) {
   printf("%-20s %.3f ms  %.1f G wave-instr/s chip  (%.2f per CU per ns; cycles/instr/SIMD at 2.4 GHz = %.2f)\n", name, ms, winstr / ms / 1e6,
          winstr / ms / 1e6 / 256, 2.4 * 4 * 256 / (winstr / ms / 1e6));
 }
-int main() { run<0>("v_fma_f32", 64); run<1>("v_pk_fma_f32", 32); run<2>("v_dot2c_f32_bf16", 64); return 0; }
+int main() { run<0>("v_fma_f32", 64); run<1>("v_pk_fma_f32", 32); run<2>("v_dot2c_f32_bf16", 64); run<3>("v_fma_mix_f32 (f16 hi)", 64); run<4>("v_and_b32", 64); return 0; }
