@@ -258,12 +258,18 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16* t, const bf
 // branch) and dt = dropout-mask(dy) (gradient of the dense output; same buffer as dy when p == 0), plus
 // column sums: dgamma, dbeta, dbias (= colsum dt).
 // out[i] += sum_p parts[p*part_stride + i]  (64 outputs x 4 waves per block; gridDim.y part-chunks, one atomic each)
+// The slab row holds up to three vectors of H columns back to back (dgamma | dbeta | dbias): ONE launch reduces all of them, the
+// output pointer is chosen per column (a NULL output is skipped).
+struct RowOuts { float* o[3]; int H; };
 template <bool ATOMIC>
 __global__ __launch_bounds__(256) void row_reduce_partials_kernel(const float* __restrict__ parts, int nparts, size_t part_stride,
-                                                                  int n, float* out) {
+                                                                  int n, RowOuts outs) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
+  const int kk = i < n ? i / outs.H : 0;
+  float* out = (kk == 0 ? outs.o[0] : kk == 1 ? outs.o[1] : outs.o[2]);
+  if (out) out -= (size_t)kk * outs.H;          // so that out[i] addresses column i - kk*H of vector kk
   float a0 = 0.f, a1 = 0.f;
   if (i < n) {
     const int step = gridDim.y * 4;
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256) void row_reduce_partials_kernel(const float* _
   }
   red[wv][lane] = a0 + a1;
   __syncthreads();
-  if (wv == 0 && i < n) {
+  if (wv == 0 && i < n && out) {
     const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     if (ATOMIC) atomicAdd(out + i, t);
     else out[i] += t;          // deterministic mode: one workgroup per output, fixed order
@@ -631,17 +637,15 @@ extern "C" int mmsim_ln_bwd(const void* dh_a, const void* dh_b, const void* y, c
   else if (nc == 4) LN_BWD_LAUNCH(4); else LN_BWD_LAUNCH(8);
   }
 #undef LN_BWD_LAUNCH
-  float* outs[3] = {dgamma, dbeta, dbias};
+  RowOuts outs;
+  outs.o[0] = dgamma; outs.o[1] = dbeta; outs.o[2] = dbias; outs.H = H;
   int gy = nblk / 16; if (gy > 8) gy = 8; if (gy < 1) gy = 1;
-  for (int k = 0; k < 3; ++k)
-    if (outs[k]) {
-      if (mmsim_deterministic())
-        hipLaunchKernelGGL(row_reduce_partials_kernel<false>, dim3((H + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream,
-                           scratch + (size_t)k * H, nblk, (size_t)3 * H, H, outs[k]);
-      else
-        hipLaunchKernelGGL(row_reduce_partials_kernel<true>, dim3((H + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream,
-                           scratch + (size_t)k * H, nblk, (size_t)3 * H, H, outs[k]);
-    }
+  if (mmsim_deterministic())
+    hipLaunchKernelGGL(row_reduce_partials_kernel<false>, dim3((3 * H + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream,
+                       scratch, nblk, (size_t)3 * H, 3 * H, outs);
+  else
+    hipLaunchKernelGGL(row_reduce_partials_kernel<true>, dim3((3 * H + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream,
+                       scratch, nblk, (size_t)3 * H, 3 * H, outs);
   return mmsim_check_launch("ln_bwd");
 }
 
