@@ -153,11 +153,17 @@ __global__ __launch_bounds__(256, 3) void dwt_fwd_kernel(const bf16* in, const f
           const int i = i0 + q * g.NP;
           if (i < npix) {
             if (XF) {       // a1 = silu(bn(z1)), rounded to bf16 as the stored tensor was; padding is zero AFTER the activation
-              float f[8];
-              unpackN<8>(v[q], f);
+              // a real branch, not a select: under a 5 x 5 window 40-60 % of a 14^2 / 7^2 tile's staged pixels are padding, and a
+              // wave whose pixels are all outside the image skips the transcendentals altogether
+              if (ok[q]) {
+                float f[8];
+                unpackN<8>(v[q], f);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) f[e] = ok[q] ? silu_f(f[e] * sc[e] + sh[e]) : 0.f;
-              v[q] = packN<8>(f);
+                for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e] * sc[e] + sh[e]);
+                v[q] = packN<8>(f);
+              } else {
+                v[q] = make_uint4(0, 0, 0, 0);
+              }
             }
             tile[(size_t)i * g.OG + u] = v[q];
           }
@@ -331,14 +337,18 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
         for (int q = 0; q < NQ; ++q) {
           const int i = i0 + q * g.NP;
           if (i < npix) {
-            float d[8], z[8], o[8];
-            unpackN<8>(vd[q], d); unpackN<8>(vz[q], z);
+            uint4 ov = make_uint4(0, 0, 0, 0);
+            if (ok[q]) {      // a real branch: waves whose pixels are all padding skip the arithmetic (see dwt_fwd_kernel)
+              float d[8], z[8], o[8];
+              unpackN<8>(vd[q], d); unpackN<8>(vz[q], z);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float da = (d[e] * gs[e] + qs[e]) * silu_grad_f(z[e] * sc2[e] + sh2[e]);
-              o[e] = ok[q] ? da - A[e] - z[e] * Bc[e] : 0.f;
+              for (int e = 0; e < 8; ++e) {
+                const float da = (d[e] * gs[e] + qs[e]) * silu_grad_f(z[e] * sc2[e] + sh2[e]);
+                o[e] = da - A[e] - z[e] * Bc[e];
+              }
+              ov = packN<8>(o);
             }
-            tile[(size_t)i * g.OG + u] = packN<8>(o);
+            tile[(size_t)i * g.OG + u] = ov;
           }
         }
       }
