@@ -60,6 +60,15 @@ int mmsim_gemm_bf16_wgrad_pair(int M1, int M2, int N, int K, const void* A1, int
                                int ldc1, const void* A2, int lda2, const void* B2, int ldb2, float* C2, int ldc2, int split_k,
                                void* stream);
 
+/* Weight gradient AND bias gradient of a dense layer from one pass over dY (autograd of nn.Linear, modeling_bert.py:334-351 for
+ * intermediate.dense):  C[M,N] (fp32) += A^T B  with A = dY stored [K][M], B = X stored [K][N], split-K atomics, and
+ * colsum[M] (fp32) += sum_k A[k][m]  (two extra MFMAs per 32-deep step against an all-ones operand in the tile-column-0 blocks)
+ * -- instead of mmsim_gemm_bf16 + a separate mmsim_colsum_bf16 pass over dY.  Shapes: mmsim_gemm_bf16_wgrad_colsum_eligible
+ * (M, N multiples of 256, K / split multiples of 64, enough tiles for the pipelined 256 x 256 kernel). */
+int mmsim_gemm_bf16_wgrad_colsum_eligible(int M, int N, int K, int split_k);
+int mmsim_gemm_bf16_wgrad_colsum(int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C, int ldc,
+                                 float* colsum, int split_k, void* stream);
+
 /* 1x1 conv whose input is the previous BatchNorm + SiLU (+ squeeze-excite gate) applied while the operand is
  * staged: x -> silu(xf_scale[c] x + xf_shift[c]) * xf_gate[pixel / xf_hw, c]  (gate may be NULL); with xf_scale = xf_shift =
  * NULL the operand is already activated (mmsim_pool_bn_act_store) and only x -> x * gate remains.

@@ -356,9 +356,8 @@ class BertModel(nn.Module):
             ops.gemm(dT, ws.u[li], G(p + "output.dense.weight"), trans_a=True, b_kmajor=False, split_k=skI, accumulate=True)
             ops.gemm(dT, SV(p + "output.dense.weight"), ws.du, b_kmajor=False, epilogue=ops.EPI_MUL if _GELU_PAIR else ops.EPI_MUL_GELU_GRAD,
                      aux_in=ws.upre[li])
-            ops.colsum(ws.du, G(p + "intermediate.dense.bias"))
-            ops.gemm(ws.du, ws.h1[li], G(p + "intermediate.dense.weight"), trans_a=True, b_kmajor=False, split_k=skI,
-                     accumulate=True)
+            # dW and the bias gradient of intermediate.dense from ONE pass over du (the column sums ride on the weight-gradient MFMAs)
+            ops.gemm_wgrad_colsum(ws.du, ws.h1[li], G(p + "intermediate.dense.weight"), G(p + "intermediate.dense.bias"), skI)
             ops.gemm(ws.du, SV(p + "intermediate.dense.weight"), ws.dhb, b_kmajor=False)
             # ---- attention-output LayerNorm: dh1 = dy2 (residual) + dhb
             dy1 = ws.dy[1]

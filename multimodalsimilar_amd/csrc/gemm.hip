@@ -314,7 +314,7 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
                      int ldb, void* C, int ldc, int c_is_f32, const float* bias, int epilogue,
                      const void* aux_in, void* aux_out, int ld_aux, float alpha, int split_k,
                      int accumulate, int xf_operand, const float* xf_scale, const float* xf_shift, const float* xf_gate,
-                     int xf_hw, void* stream, float* stats = nullptr) {
+                     int xf_hw, void* stream, float* stats = nullptr, float* colsum = nullptr) {
   MMSIM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: M, N, K must be positive");
   MMSIM_REQUIRE(A && B && C, "gemm: null operand");
   MMSIM_REQUIRE((lda % 8) == 0 && (ldb % 8) == 0, "gemm: lda/ldb must be multiples of 8 elements (16-byte rows)");
@@ -342,7 +342,7 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   p.c_f32 = c_is_f32; p.epi = epilogue; p.atomic = split_k > 1; p.accum = accumulate; p.alpha = alpha;
   p.xf_scale = xf_scale; p.xf_shift = xf_shift; p.xf_gate = xf_gate; p.xf_hw = xf_hw > 0 ? xf_hw : 1; p.xf_dhw = make_fastdiv(p.xf_hw);
   p.xf_C = (xf_operand == 1) ? K : N;
-  p.stats = stats; p.band = 1;
+  p.stats = stats; p.band = 1; p.colsum = colsum;
 #ifdef MMSIM_ABLATE     // ablation object only (tools/bench_gemm_abl.py); the product library never reads this variable
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MMSIM_GEMM_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
 #else
@@ -357,6 +357,8 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   dim3 grid(p.tiles_m * p.tiles_n * splits), block(256);
   const size_t lds = 2 * STAGE_BYTES;
   hipStream_t s = (hipStream_t)stream;
+  MMSIM_REQUIRE(!colsum || (trans_a && !b_kmajor && xf_operand == 0 && !stats && !force_generic() && gemm_fast_eligible(p, splits)),
+                "gemm: the fused column sum needs the pipelined weight-gradient kernel");
   if (xf_operand == 0 && !stats && !force_generic() && gemm_fast_eligible(p, splits)) {
     if (g_group.active) { const int rc = group_flush(); if (rc) return rc; }
     gemm_fast_launch(p, trans_a, b_kmajor, splits, s);
@@ -424,6 +426,29 @@ extern "C" int mmsim_gemm_group_end(void) {
   const int rc = group_flush();
   g_group.active = false;
   return rc;
+}
+
+// Weight gradient of a dense layer AND its bias gradient from one pass over dY:  C[M,N] (fp32) += A^T B  with A = dY stored [K][M],
+// B = X stored [K][N] (split-K atomics), and colsum[M] += sum_k A[k][m].  Only for products the pipelined 256 x 256 kernel takes
+// (M, N multiples of 256, K of 64 per split, >= 128 tiles x splits); the caller falls back to mmsim_gemm_bf16 + mmsim_colsum_bf16 when
+// mmsim_gemm_bf16_wgrad_colsum_eligible says no.
+extern "C" int mmsim_gemm_bf16_wgrad_colsum_eligible(int M, int N, int K, int split_k) {
+  if (M <= 0 || N <= 0 || K <= 0 || split_k < 1 || (M % 256) || (N % 256)) return 0;
+  if (mmsim_deterministic()) split_k = 1;
+  int kps = (K + split_k - 1) / split_k;
+  kps = ((kps + BK - 1) / BK) * BK;
+  const int splits = (K + kps - 1) / kps;
+  if ((K % 64) || (kps % 64)) return 0;
+  const int t256 = (M / 256) * (N / 256);
+  return (t256 >= 32 && t256 * splits >= 160) ? 1 : 0;      // the shapes gemm_fast_launch sends to gemm_pp64_kernel<true,false,256>
+}
+extern "C" int mmsim_gemm_bf16_wgrad_colsum(int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C, int ldc,
+                                            float* colsum, int split_k, void* stream) {
+  MMSIM_REQUIRE(colsum, "gemm_wgrad_colsum: colsum required");
+  MMSIM_REQUIRE(mmsim_gemm_bf16_wgrad_colsum_eligible(M, N, K, split_k), "gemm_wgrad_colsum: shape not eligible (see _eligible)");
+  MMSIM_REQUIRE(!force_generic(), "gemm_wgrad_colsum: MMSIM_GEMM_GENERIC=1 disables the pipelined kernel this entry point needs");
+  return gemm_impl(1, 0, M, N, K, A, lda, B, ldb, C, ldc, 1, nullptr, 0, nullptr, nullptr, 0, 1.0f, split_k, 1, 0, nullptr, nullptr,
+                   nullptr, 1, stream, nullptr, colsum);
 }
 
 extern "C" int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B,

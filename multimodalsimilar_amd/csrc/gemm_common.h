@@ -15,6 +15,10 @@ struct GemmParams {
   // >= tiles_m1 belong to it (A2 / B2 / C2).  Used to run the attention-output and the q|k|v weight gradients of a layer as
   // one 256-block launch (16 + 48 output tiles x 4 splits) instead of two launches that each under-fill the chip.
   const bf16* A2; const bf16* B2; void* C2; int lda2, ldb2, ldc2, tiles_m1;
+  // gemm_pp64_kernel<true, false, 256>: column sums of the transposed operand A ([K][M]: sum over k of A[k][m]) accumulated
+  // atomically into colsum[M] by the tile column 0 blocks -- the bias gradient of a dense layer out of its weight-gradient
+  // product (A = dY), instead of a separate pass over dY (NULL = off)
+  float* colsum;
   int dbg;   // ablation object only (-DMMSIM_ABLATE): 1 no DMA, 4 no MFMA, 8 no epilogue; the product build ignores it
 };
 

@@ -263,6 +263,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
+  // bias gradient riding on the weight-gradient product (GemmParams::colsum): in the tile-column-0 blocks wave (wm, wn) also sums
+  // the A rows of its sub-tiles 2 wn, 2 wn + 1 over k with two extra MFMAs per 32-deep step against an all-ones operand
+  constexpr bool COLSUM_OK = TA && !TB_KMAJOR && BN == 256 && !GRP;
+  const bool do_colsum = COLSUM_OK && p.colsum != nullptr && tn == 0;
+  f4 bacc[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
+  bf8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
   const bool dma_on = !(PP64_DBG(p) & 1);
   if (dma_on) {
     dma_tile<TA, GBM>(gA, glda, m0, kbeg, smem, wave, lane);
@@ -289,6 +297,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                       \
       _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);          \
+    if constexpr (COLSUM_OK) {                                                                           \
+      if (do_colsum) {            /* wave-uniform; af[] indexed with compile-time constants only */        \
+        if (wn == 0) { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[0], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[1], bacc[1], 0, 0, 0); } \
+        else if (wn == 1) { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[2], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[3], bacc[1], 0, 0, 0); } \
+        else if (wn == 2) { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 4 : 0], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 5 : 1], bacc[1], 0, 0, 0); } \
+        else { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 6 : 2], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 7 : 3], bacc[1], 0, 0, 0); } \
+      }                                                                                                  \
+    }                                                                                                    \
   }                                                                                                      \
   __builtin_amdgcn_sched_barrier(0);
   for (int u = 0; u < ns; ++u) {
@@ -318,6 +334,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
 #undef PP64_READ
 #undef PP64_MFMA
   if (grp == 0) __builtin_amdgcn_s_barrier();            // both groups have now executed 4 ns + 1 barriers
+  if constexpr (COLSUM_OK) {
+    // bacc[s][e] = sum_k A[k][m] for m = row (lane & 15) of sub-tile 2 wn + s, the same value in every column e / lane group
+    if (do_colsum && (lane >> 4) == 0) {
+      float* dst = p.colsum + m0 + wm * WROWS + (2 * wn) * 16 + (lane & 15);
+      atomicAdd(dst, bacc[0][0]);
+      atomicAdd(dst + 16, bacc[1][0]);
+    }
+  }
   const bool fs = split == 0;
   float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
   if (PP64_DBG(p) & 8) {
@@ -400,6 +424,7 @@ static void launch_pipe(GemmParams p, int trans_a, int b_kmajor, int splits, hip
 }
 
 void gemm_fast_launch(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s) {
+  if (p.colsum) { launch_pipe<256>(p, trans_a, b_kmajor, splits, s); return; }      // only this kernel sums the columns (host checked the shape)
   const int pref = tile_pref();
   // wgrad-shaped products (A transposed: few output tiles, long reduction, split-K) take the narrower tile: more tiles
   // per split and half the atomic traffic per block; everything else prefers 256x256 (twice the flop per staged byte)

@@ -306,6 +306,26 @@ def ln_bwd(dh_a, dh_b, y, mean, rstd, gamma, dy, dt, dgamma, dbeta, dbias, dropo
                _p(dbias), M, H, float(dropout_p), seed, stream_id, _p(scr), scr.numel(), _stream())
 
 
+def gemm_wgrad_colsum(dy, x, dw, dbias, split_k):
+    """dw[M,N] += dy^T x  and  dbias[M] += column sums of dy, one pass over dy (dy: [K, M], x: [K, N] bf16; dw, dbias f32); falls back
+    to the two separate launches when the shape does not take the pipelined kernel (mmsim_gemm_bf16_wgrad_colsum_eligible)."""
+    _chk(dy, BF16, "gemm_wgrad_colsum.dy", 2); _chk(x, BF16, "gemm_wgrad_colsum.x", 2)
+    _chk(dw, F32, "gemm_wgrad_colsum.dw", 2); _chk(dbias, F32, "gemm_wgrad_colsum.dbias", 1)
+    K, M = dy.shape
+    N = x.shape[1]
+    if x.shape[0] != K or tuple(dw.shape) != (M, N) or dbias.numel() != M:
+        raise ValueError("gemm_wgrad_colsum: shape mismatch")
+    if _WGRAD_COLSUM and lib.gemm_bf16_wgrad_colsum_eligible(M, N, K, int(split_k)):
+        lib.gemm_bf16_wgrad_colsum(M, N, K, _p(dy), _ld(dy), _p(x), _ld(x), _p(dw), _ld(dw), _p(dbias), int(split_k), _stream())
+    else:
+        colsum(dy, dbias)
+        gemm(dy, x, dw, trans_a=True, b_kmajor=False, split_k=split_k, accumulate=True)
+
+
+# MMSIM_WGRAD_COLSUM=0: bias gradient of intermediate.dense by the separate column-sum pass (A/B switch)
+_WGRAD_COLSUM = os.environ.get("MMSIM_WGRAD_COLSUM", "1") != "0"
+
+
 def colsum(x, out):
     _chk(x, BF16, "colsum.x", 2); _chk(out, F32, "colsum.out", 1)
     lib.colsum_bf16(_p(x), _ld(x), _p(out), x.shape[0], x.shape[1], _stream())

@@ -467,3 +467,24 @@ def test_head_gradient_after_a_lazy_zero_grad_equals_the_eager_one():
     loss, _ = m0.forward_loss(x.clone().requires_grad_(True), label); loss.backward()
     o0.zero_grad(); o0.step()
     assert torch.equal(m0.weight.detach(), m1.weight.detach()) and not torch.equal(w_before, m1.weight.detach())
+
+
+@pytest.mark.parametrize("M,N,K,sk", [(4096, 1024, 4096, 4), (4096, 2048, 2048, 2)])
+def test_weight_gradient_with_fused_bias_gradient(M, N, K, sk):
+    """mmsim_gemm_bf16_wgrad_colsum: dW += dY^T X and dbias += column sums of dY from one pass over dY (the column sums ride on the
+    weight-gradient MFMAs against an all-ones operand), against the two separate launches and fp32 torch; both accumulate."""
+    from multimodalsimilar_amd import ops
+    from multimodalsimilar_amd._lib import lib
+    assert lib.gemm_bf16_wgrad_colsum_eligible(M, N, K, sk)
+    dy = rnd(K, M, seed=1).bfloat16()
+    x = rnd(K, N, seed=2).bfloat16()
+    w0, b0 = rnd(M, N, seed=3), rnd(M, seed=4)
+    dw, db = w0.clone(), b0.clone()
+    ops.gemm_wgrad_colsum(dy, x, dw, db, sk)
+    assert relerr(dw - w0, dy.float().t() @ x.float()) < 2e-3
+    assert relerr(db - b0, dy.float().sum(0)) < 1e-4
+    dw2, db2 = w0.clone(), b0.clone()
+    ops.colsum(dy, db2)
+    ops.gemm(dy, x, dw2, trans_a=True, b_kmajor=False, split_k=sk, accumulate=True)
+    assert relerr(dw - w0, dw2 - w0) < 1e-4 and relerr(db - b0, db2 - b0) < 1e-4
+    assert not lib.gemm_bf16_wgrad_colsum_eligible(M + 8, N, K, sk) and not lib.gemm_bf16_wgrad_colsum_eligible(256, 256, K, 1)
