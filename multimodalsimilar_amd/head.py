@@ -88,13 +88,24 @@ class ArcMarginProduct(nn.Module):
         C, D = self.out_feature, self.in_feature
         if not _FUSED_NORM or not self.weight.is_cuda or D % 4 or D > 4096:
             return None
-        return C, D, self._buf("wh", (C, D), torch.bfloat16), self._buf("inv_w", (C,), torch.float32)
+        return C, D, self._wh_buf()[:C], self._buf("inv_w", (C,), torch.float32)
 
     def mark_normalised(self):
         self._wh_key = (self.weight._version, self.weight.data_ptr())
 
     def invalidate_normalised(self):
         self._wh_key = None
+
+    def _cpad(self):
+        """Class dimension of the scratch buffers (w_hat rows, cos / dcos leading dimension).  Large heads round it up to a multiple of
+        256 so that the cosine product [B, C] and dxh = dcos w_hat (reduction over C) are tile-aligned for the pipelined LDS-DMA GEMM
+        (C = 100 000 -> 100 096: zero rows of w_hat give zero cosines, zero pad columns of dcos add nothing); both products stream
+        the 563 MB w_hat and ran the ragged-shape kernel at 1.7-1.9 TB/s, exposed between the towers' forward and backward."""
+        C = self.out_feature
+        return ops.round_up(C, 256) if C >= 4096 else ops.round_up(C, 8)
+
+    def _wh_buf(self):
+        return self._buf("wh", (self._cpad(), self.in_feature), torch.bfloat16, zero=True)      # rows >= C stay zero
 
     def _buf(self, name, shape, dtype, zero=False):
         key = (name, tuple(shape), dtype)
@@ -113,8 +124,9 @@ class ArcMarginProduct(nn.Module):
             raise ValueError(f"ArcMarginProduct: expected x [B, {self.in_feature}], got {tuple(x.shape)}")
         B, D, C = x.shape[0], self.in_feature, self.out_feature
         x = x.contiguous().float()
-        ldc = ops.round_up(C, 8)
-        wh = self._buf("wh", (C, D), torch.bfloat16)
+        ldc = self._cpad()
+        whp = self._wh_buf()                                                         # [ldc, D], rows >= C zero
+        wh = whp[:C]
         inv_w = self._buf("inv_w", (C,), torch.float32)
         xh = self._buf("xh", (B, D), torch.bfloat16)
         inv_x = self._buf("inv_x", (B,), torch.float32)
@@ -125,8 +137,8 @@ class ArcMarginProduct(nn.Module):
             ops.l2norm_fwd(self.weight.detach(), None, wh, 0, inv_w)                 # F.normalize(self.weight)
             self._wh_key = key
         ops.l2norm_fwd(x, None, xh, 0, inv_x)                                        # F.normalize(x)
-        ops.gemm(xh, wh, cos[:, :C])                                                 # F.linear  (arcface.py:47)
-        return cos, dict(x=x, xh=xh, wh=wh, inv_x=inv_x, inv_w=inv_w, B=B, ldc=ldc, gen=self._gen)
+        ops.gemm(xh, whp, cos)                                                       # F.linear  (arcface.py:47); pad columns = 0
+        return cos, dict(x=x, xh=xh, wh=wh, whp=whp, inv_x=inv_x, inv_w=inv_w, B=B, ldc=ldc, gen=self._gen)
 
     def _check_gen(self, st):
         # xh / inv_x / cos / dcos are module scratch reused by the next call: a backward that runs after another forward
@@ -144,10 +156,10 @@ class ArcMarginProduct(nn.Module):
         dxh = self._buf("dxh", (B, D), torch.float32)
         dx = torch.empty((B, D), dtype=torch.float32, device=dcos.device)
         # dxh = dcos @ Wh: 2 x 22 output tiles over a 100k-long reduction -> split-K (fp32 atomics into the zeroed buffer)
-        sk = ops.pick_split_k(B, D, C)
+        sk = ops.pick_split_k(B, D, ldc)
         if sk > 1:
             dxh.zero_()
-        ops.gemm(dcos[:, :C], st["wh"], dxh, b_kmajor=False, split_k=sk, accumulate=sk > 1)
+        ops.gemm(dcos, st["whp"], dxh, b_kmajor=False, split_k=sk, accumulate=sk > 1)      # over the padded class range (zeros)
         ops.l2norm_bwd(st["x"], st["inv_x"], dxh, 0, dx)
         # this product writes every element of the head's gradient buffer: after a lazy zero_grad it overwrites (no fill, no read)
         acc = not self._flat.take_zero_pending()

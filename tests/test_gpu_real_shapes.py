@@ -137,7 +137,7 @@ def test_head_at_one_million_classes_properties():
     assert 0 <= int(am.min()) and int(am.max()) < C
     # softmax-gradient rows sum to zero: dcos / (s slope) = (p - onehot) / B.  Off-target slope = 1, so row sums of dcos equal
     # -(1 - p_y)(slope_y - 1) s / B ... checked in the slope-free form: every entry except the label column is positive
-    dcos = head._buf("dcos", (B, (C + 7) // 8 * 8), torch.bfloat16)[:, :C].float()
+    dcos = head._buf("dcos", (B, head._cpad()), torch.bfloat16)[:, :C].float()      # leading dimension: C rounded up to 256 (zero pad)
     neg = (dcos < 0).sum(1)
     assert int(neg.max()) == 1 and int(neg.min()) == 1
     assert torch.equal(dcos.argmin(1), y)
