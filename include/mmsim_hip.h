@@ -242,6 +242,12 @@ int mmsim_bn_bwd(const void* dy, const void* z, const float* mean, const float* 
                  const float* shift, const float* gate, const float* dsq, int hw, int act_silu, float* sums,
                  int sums_ready, void* dz, float* dgamma, float* dbeta, int P, int C, float* scratch,
                  unsigned long long scratch_floats, void* stream);
+/* The two layout transforms below for ALL depthwise layers of a network in one launch: segs_dev = device array of nseg x 4 int64
+ * {src offset, dst offset, C, K*K} (offsets in floats from src_base / dst_base).  to_tap_major 1: weights [C][K*K] -> [K*K][C];
+ * 0: tap-major gradient ACCUMULATED into the [C][K*K] gradient.  max_elems = the largest C * K*K (grid sizing). */
+int mmsim_dw_tap_major_batch(const void* segs_dev, int nseg, const float* src_base, float* dst_base, int to_tap_major,
+                             int max_elems, void* stream);
+
 /* Depthwise k3/k5 stride 1/2 conv, pad k/2.  Weights in tap-major fp32 [K*K][C] (see the two converters).
  * fwd also accumulates the output's BN sums; bwd_data also applies silu'(bn(z1)) of the producer and
  * accumulates that BatchNorm's backward sums (z1 == NULL: plain transposed conv, + resid if given);

@@ -600,6 +600,22 @@ __global__ void dw_grad_from_tap_major_kernel(const float* gT, float* g, int C, 
   if (i < C * KK) { const int c = i / KK, t = i % KK; g[i] += gT[(size_t)t * C + c]; }
 }
 
+// All depthwise layers of a network in ONE launch each way: segs[s] = {src offset, dst offset, C, K*K} (offsets in floats from the two
+// base pointers; the flat parameter / gradient buffers and one contiguous tap-major buffer).  blockIdx.y = segment.
+//   to_tap_major = 1:  dst[t*C + c]  = src[c*KK + t]      (weights [C][KK] -> wT [KK][C], once per step)
+//   to_tap_major = 0:  dst[c*KK + t] += src[t*C + c]      (tap-major gradient -> the parameter's gradient, once per backward)
+__global__ void dw_tap_major_batch_kernel(const long long* __restrict__ segs, const float* __restrict__ src_base, float* dst_base,
+                                          int to_tap_major) {
+  const long long so = segs[blockIdx.y * 4 + 0], dof = segs[blockIdx.y * 4 + 1];
+  const int C = (int)segs[blockIdx.y * 4 + 2], KK = (int)segs[blockIdx.y * 4 + 3];
+  const int n = C * KK;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int c = i / KK, t = i - c * KK;
+    if (to_tap_major) dst_base[dof + (size_t)t * C + c] = src_base[so + i];
+    else dst_base[dof + i] += src_base[so + (size_t)t * C + c];
+  }
+}
+
 struct DwGeom { int B, Hi, Wi, Ho, Wo, C; FastDiv d_strip, d_rows; };   // d_strip / d_rows: strips per row, rows per image of the item space
 
 // forward: a [B,Hi,Wi,C] -> z [B,Ho,Wo,C]; fused per-channel sum / sumsq of z (bf16-rounded) for the next BN.
@@ -1421,6 +1437,15 @@ static int dwconv_bwd_weight_impl(const void* dz, const void* a, const float* xf
   DW_DISPATCH(dwconv_bwd_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, (const bf16*)a, scratch, g, rpb, xf_scale, xf_shift)
   launch_reduce(scratch, grid.x, K * K * C, g_tap_major, 1, (hipStream_t)stream);      /* g_tap_major += */
   return mmsim_check_launch("dwconv_bwd_weight");
+}
+
+extern "C" int mmsim_dw_tap_major_batch(const void* segs_dev, int nseg, const float* src_base, float* dst_base, int to_tap_major,
+                                        int max_elems, void* stream) {
+  MMSIM_REQUIRE(segs_dev && src_base && dst_base && nseg > 0 && max_elems > 0, "dw_tap_major_batch: bad arguments");
+  int gx = (max_elems + 255) / 256; if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(dw_tap_major_batch_kernel, dim3(gx, nseg), dim3(256), 0, (hipStream_t)stream, (const long long*)segs_dev, src_base,
+                     dst_base, to_tap_major);
+  return mmsim_check_launch("dw_tap_major_batch");
 }
 
 extern "C" int mmsim_stem_fwd(const float* x, const float* w, void* z, float* sums, int B, int Hi, int Wi, int Co, float* scratch,

@@ -326,8 +326,10 @@ class EfficientNet(nn.Module):
             bs.a1 = cur
         Ho, Wo = (H + b.stride - 1) // b.stride, (W + b.stride - 1) // b.stride
         P_out = B * Ho * Wo
-        bs.wT = E(b.k * b.k, b.mid, dt=torch.float32)
-        lib.dw_weight_to_tap_major(V(n + ".conv_dw.weight").data_ptr(), bs.wT.data_ptr(), b.mid, b.k, s)
+        if not hasattr(st, "wT_all"):             # a block driven on its own (tests): _run_forward makes this copy for all blocks at once
+            self._make_wT(st, cur.device, s)
+        o = self._tap_off[n]                      # tap-major copy of the depthwise weights
+        bs.wT = st.wT_all[o:o + b.k * b.k * b.mid].view(b.k * b.k, b.mid)
         bs.z2 = E(P_out, b.mid)
         sm = self._sums(st, n + "." + d_bn, "f")
         if not _DWTILE:
@@ -390,6 +392,7 @@ class EfficientNet(nn.Module):
         self._gen = getattr(self, "_gen", 0) + 1      # BN statistics live in module scratch (bnstat): see _run_backward
         st = SimpleNamespace(B=B, Hi=Hi, Wi=Wi, x=x, blocks=[], gen=self._gen)
         st.bnstat = self._buf("bnstat", (4, self._bn_total), torch.float32)
+        self._make_wT(st, dev, s)
         st.sums_f = self._buf("sums_f", (2 * self._bn_total,), torch.float32)
         st.sums_f.zero_()
         E = lambda *sh, dt=bf: torch.empty(*sh, dtype=dt, device=dev)
@@ -425,6 +428,31 @@ class EfficientNet(nn.Module):
         return st
 
     # ------------------------------------------------------------------ backward
+    def _tap_tables(self, dev):
+        """Segment tables of mmsim_dw_tap_major_batch: every block's conv_dw.weight <-> its slice of the contiguous tap-major buffers."""
+        if getattr(self, "_tap_dev", None) == dev:
+            return
+        fl = self._flat
+        self._tap_off, fwd, bwd, tot, mx = {}, [], [], 0, 0
+        for blk in self.arch.blocks:
+            kk, po = blk.k * blk.k, fl.offsets[blk.name + ".conv_dw.weight"]
+            self._tap_off[blk.name] = tot
+            fwd.append([po, tot, blk.mid, kk])          # master weights -> wT_all
+            bwd.append([tot, po, blk.mid, kk])          # gT_all -> gradient buffer
+            tot += kk * blk.mid
+            mx = max(mx, kk * blk.mid)
+        self._tap_total, self._tap_max = tot, mx
+        self._tap_fwd = torch.tensor(fwd, dtype=torch.int64, device=dev)
+        self._tap_bwd = torch.tensor(bwd, dtype=torch.int64, device=dev)
+        self._tap_dev = dev
+
+    def _make_wT(self, st, dev, s):
+        """Tap-major fp32 copies of every block's depthwise weights: one launch per forward."""
+        self._tap_tables(dev)
+        st.wT_all = self._buf("wT_all", (self._tap_total,), torch.float32)
+        lib.dw_tap_major_batch(self._tap_fwd.data_ptr(), len(self.arch.blocks), self._flat.master.data_ptr(), st.wT_all.data_ptr(), 1,
+                               self._tap_max, s)
+
     def _zero_gT(self, st):
         """Tap-major depthwise weight gradients of all blocks: one zeroed buffer per step instead of a fill per block."""
         st.gT_off, tot = {}, 0
@@ -522,7 +550,8 @@ class EfficientNet(nn.Module):
                                          gT.data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride, *self._scr(), s)
             else:
                 lib.dwconv_bwd_weight(dz2.data_ptr(), bs.a1.data_ptr(), gT.data_ptr(), B, Hn, Wn, b.mid, b.k, b.stride, *self._scr(), s)
-        lib.dw_grad_from_tap_major(gT.data_ptr(), G(n + ".conv_dw.weight").data_ptr(), b.mid, b.k, s)
+        if not getattr(st, "tap_batched", False):      # data parallel (this block's gradient range is reported below and must be
+            lib.dw_grad_from_tap_major(gT.data_ptr(), G(n + ".conv_dw.weight").data_ptr(), b.mid, b.k, s)      # final), or a lone block
         if b.type == "ir":
             en = n + "." + e_bn
             if not fused:
@@ -590,8 +619,11 @@ class EfficientNet(nn.Module):
             ops.gemm(dzh, SV("conv_head.weight", (a.head, a.last)), dx, b_kmajor=False)
         del dyh, dzh
         # ---- blocks, last to first
+        st.tap_batched = not self.grad_ready_hook
         for b, bs in zip(reversed(a.blocks), reversed(st.blocks)):
             dx = self._block_bwd(st, b, bs, dx)
+        if st.tap_batched:      # every block's tap-major depthwise weight gradient into the gradient buffer, one launch
+            lib.dw_tap_major_batch(self._tap_bwd.data_ptr(), len(a.blocks), st.gT_all.data_ptr(), fl.grad.data_ptr(), 0, self._tap_max, s)
         # ---- stem
         P0 = B * (st.Hi // 2) * (st.Wi // 2)
         dz0 = E(P0, a.stem)
