@@ -228,7 +228,9 @@ int mmsim_bn_bwd_sums_from_pool(const float* out5, const float* gate, const floa
 /* Squeeze-excite: hr = W_reduce s + b_reduce (saved pre-activation; hs = silu(hr) saved too); gate = sigmoid(W_expand silu(hr) + b_expand).
  * weT [RD][C] receives conv_expand.weight transposed (kept for the backward of the same step).  Backward: from
  * dgate [B,C] produces dr [B,RD], ds [B,C] (gradient of the squeezed input) and accumulates the four parameter
- * gradients (dweT [RD][C]: scratch). */
+ * gradients (dweT [RD][C]: scratch).  w_expand = NULL (forward): weT already holds the transposed weights; dw_expand = NULL
+ * (backward): dweT is the caller's ZEROED buffer and receives the transposed expand-weight gradient (accumulated; the caller
+ * transposes it into the parameter's gradient, e.g. for all blocks at once with mmsim_dw_tap_major_batch). */
 int mmsim_se_mlp_fwd(const float* s, const float* w_reduce, const float* b_reduce, const float* w_expand,
                      const float* b_expand, float* weT, float* hr, float* hs, float* gate, int B, int C, int RD,
                      void* stream);

@@ -1288,10 +1288,11 @@ extern "C" int mmsim_bn_bwd_sums_from_pool(const float* out5, const float* gate,
 extern "C" int mmsim_se_mlp_fwd(const float* s, const float* w_reduce, const float* b_reduce, const float* w_expand,
                                 const float* b_expand, float* weT, float* hr, float* hs, float* gate, int B, int C, int RD,
                                 void* stream) {
-  MMSIM_REQUIRE(s && w_reduce && b_reduce && w_expand && b_expand && weT && hr && hs && gate && B > 0 && C > 0 && RD > 0, "se_mlp_fwd: bad arguments");
+  MMSIM_REQUIRE(s && w_reduce && b_reduce && b_expand && weT && hr && hs && gate && B > 0 && C > 0 && RD > 0, "se_mlp_fwd: bad arguments");
   MMSIM_REQUIRE(C % 8 == 0 && RD <= 128, "se_mlp_fwd: C must be a multiple of 8 and RD <= 128");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(se_transpose_kernel, dim3((C * RD + 255) / 256), dim3(256), 0, st, w_expand, weT, C, RD, 0);
+  if (w_expand)        // NULL: weT already holds conv_expand.weight transposed (made for all blocks at once, mmsim_dw_tap_major_batch)
+    hipLaunchKernelGGL(se_transpose_kernel, dim3((C * RD + 255) / 256), dim3(256), 0, st, w_expand, weT, C, RD, 0);
   hipLaunchKernelGGL(se_rowdot_kernel, dim3(RD, (B + 7) / 8), dim3(256), 0, st, w_reduce, s, (const float*)nullptr, b_reduce,
                      (const float*)nullptr, hr, hs, B, C, RD, SE_PRE_NONE, SE_POST_NONE);
   hipLaunchKernelGGL(se_colmix_kernel, dim3((C + 63) / 64, (B + 3) / 4), dim3(256), 0, st, weT, hr, b_expand, gate, B, C, RD, SE_PRE_SILU,
@@ -1303,7 +1304,7 @@ extern "C" int mmsim_se_mlp_fwd(const float* s, const float* w_reduce, const flo
 extern "C" int mmsim_se_mlp_bwd(const float* dgate, const float* gate, const float* hr, const float* hs, const float* s,
                                 const float* w_reduce, const float* weT, float* dr, float* ds, float* dweT, float* dw_reduce,
                                 float* db_reduce, float* dw_expand, float* db_expand, int B, int C, int RD, void* stream) {
-  MMSIM_REQUIRE(dgate && gate && hr && hs && s && w_reduce && weT && dr && ds && dweT && dw_reduce && db_reduce && dw_expand && db_expand,
+  MMSIM_REQUIRE(dgate && gate && hr && hs && s && w_reduce && weT && dr && ds && dweT && dw_reduce && db_reduce && db_expand,
                 "se_mlp_bwd: null operand");
   MMSIM_REQUIRE(C % 8 == 0 && RD <= 128, "se_mlp_bwd: C must be a multiple of 8 and RD <= 128");
   hipStream_t st = (hipStream_t)stream;
@@ -1313,10 +1314,12 @@ extern "C" int mmsim_se_mlp_bwd(const float* dgate, const float* gate, const flo
   // ds[b,c] = sum_j Wr[j,c] dr[b,j]
   hipLaunchKernelGGL(se_colmix_kernel, dim3((C + 63) / 64, (B + 3) / 4), dim3(256), 0, st, w_reduce, dr, (const float*)nullptr, ds, B, C, RD,
                      SE_PRE_NONE, SE_POST_NONE);
-  (void)hipMemsetAsync(dweT, 0, (size_t)C * RD * sizeof(float), st);
+  // dw_expand NULL: dweT is the caller's zeroed accumulation buffer (transposed into the gradient for all blocks at once later);
+  // otherwise dweT is scratch: zeroed here and transposed-accumulated into dw_expand
+  if (dw_expand) (void)hipMemsetAsync(dweT, 0, (size_t)C * RD * sizeof(float), st);
   hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 63) / 64, (RD + 15) / 16, mmsim_deterministic() ? 1 : 4), dim3(64), 0, st, dgate, gate, dr, hs, s, dw_reduce, db_reduce,
                      dweT, db_expand, B, C, RD);
-  hipLaunchKernelGGL(se_transpose_kernel, dim3((C * RD + 255) / 256), dim3(256), 0, st, dweT, dw_expand, RD, C, 1);
+  if (dw_expand) hipLaunchKernelGGL(se_transpose_kernel, dim3((C * RD + 255) / 256), dim3(256), 0, st, dweT, dw_expand, RD, C, 1);
   return mmsim_check_launch("se_mlp_bwd");
 }
 

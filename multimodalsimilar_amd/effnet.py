@@ -354,9 +354,10 @@ class EfficientNet(nn.Module):
         bs.hr = E(B, b.rd, dt=torch.float32)
         bs.hs = E(B, b.rd, dt=torch.float32)
         bs.gate = E(B, b.mid, dt=torch.float32)
-        bs.weT = E(b.rd, b.mid, dt=torch.float32)
+        o = self._se_off[n]                       # conv_expand.weight transposed: made with the tap-major copies (_make_wT)
+        bs.weT = st.wT_all[o:o + b.rd * b.mid].view(b.rd, b.mid)
         lib.se_mlp_fwd(bs.s.data_ptr(), V(n + ".se.conv_reduce.weight").data_ptr(), V(n + ".se.conv_reduce.bias").data_ptr(),
-                       V(n + ".se.conv_expand.weight").data_ptr(), V(n + ".se.conv_expand.bias").data_ptr(),
+                       None, V(n + ".se.conv_expand.bias").data_ptr(),
                        bs.weT.data_ptr(), bs.hr.data_ptr(), bs.hs.data_ptr(), bs.gate.data_ptr(), B, b.mid, b.rd, s)
         pw = n + (".conv_pw" if b.type == "ds" else ".conv_pwl")
         bs.z3 = E(P_out, b.cout)
@@ -433,7 +434,7 @@ class EfficientNet(nn.Module):
         if getattr(self, "_tap_dev", None) == dev:
             return
         fl = self._flat
-        self._tap_off, fwd, bwd, tot, mx = {}, [], [], 0, 0
+        self._tap_off, self._se_off, fwd, bwd, tot, mx = {}, {}, [], [], 0, 0
         for blk in self.arch.blocks:
             kk, po = blk.k * blk.k, fl.offsets[blk.name + ".conv_dw.weight"]
             self._tap_off[blk.name] = tot
@@ -441,7 +442,14 @@ class EfficientNet(nn.Module):
             bwd.append([tot, po, blk.mid, kk])          # gT_all -> gradient buffer
             tot += kk * blk.mid
             mx = max(mx, kk * blk.mid)
-        self._tap_total, self._tap_max = tot, mx
+        for blk in self.arch.blocks:                    # the SE expand weights [mid][rd] <-> [rd][mid] ride in the same two buffers
+            po = fl.offsets[blk.name + ".se.conv_expand.weight"]
+            self._se_off[blk.name] = tot
+            fwd.append([po, tot, blk.mid, blk.rd])
+            bwd.append([tot, po, blk.mid, blk.rd])
+            tot += blk.rd * blk.mid
+            mx = max(mx, blk.rd * blk.mid)
+        self._tap_total, self._tap_max, self._tap_n = tot, mx, len(fwd)
         self._tap_fwd = torch.tensor(fwd, dtype=torch.int64, device=dev)
         self._tap_bwd = torch.tensor(bwd, dtype=torch.int64, device=dev)
         self._tap_dev = dev
@@ -450,16 +458,15 @@ class EfficientNet(nn.Module):
         """Tap-major fp32 copies of every block's depthwise weights: one launch per forward."""
         self._tap_tables(dev)
         st.wT_all = self._buf("wT_all", (self._tap_total,), torch.float32)
-        lib.dw_tap_major_batch(self._tap_fwd.data_ptr(), len(self.arch.blocks), self._flat.master.data_ptr(), st.wT_all.data_ptr(), 1,
+        lib.dw_tap_major_batch(self._tap_fwd.data_ptr(), self._tap_n, self._flat.master.data_ptr(), st.wT_all.data_ptr(), 1,
                                self._tap_max, s)
 
     def _zero_gT(self, st):
-        """Tap-major depthwise weight gradients of all blocks: one zeroed buffer per step instead of a fill per block."""
-        st.gT_off, tot = {}, 0
-        for blk in self.arch.blocks:
-            st.gT_off[blk.name] = tot
-            tot += blk.k * blk.k * blk.mid
-        st.gT_all = self._buf("gT_all", (tot,), torch.float32)
+        """Tap-major depthwise weight gradients and transposed SE expand-weight gradients of all blocks: one zeroed buffer per step
+        (same slice layout as wT_all, _tap_tables) instead of a fill per block."""
+        self._tap_tables(self._flat.master.device)
+        st.gT_off = self._tap_off
+        st.gT_all = self._buf("gT_all", (self._tap_total,), torch.float32)
         st.gT_all.zero_()
 
     def _bn_bwd(self, st, name, dy, z, P, C, dz, act, gate=None, dsq=None, hw=1, sums_ready=False):
@@ -508,11 +515,19 @@ class EfficientNet(nn.Module):
         lib.pool_bn_bwd(bs.z2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), mu2.data_ptr(), rs2.data_ptr(), da2g.data_ptr(),
                         out5.data_ptr(), B, Ho * Wo, b.mid, s)
         dgate = out5[0]
-        dr, ds, dweT = E(B, b.rd, dt=torch.float32), E(B, b.mid, dt=torch.float32), E(b.rd, b.mid, dt=torch.float32)
+        dr, ds = E(B, b.rd, dt=torch.float32), E(B, b.mid, dt=torch.float32)
+        if not hasattr(st, "gT_all"):
+            self._zero_gT(st)
+        batched = getattr(st, "tap_batched", False)
+        if batched:       # the transposed expand-weight gradient lands in its slice of the zeroed gT_all; transposed back with all the others
+            o = self._se_off[n]
+            dweT = st.gT_all[o:o + b.rd * b.mid]
+        else:             # data parallel (the block's gradient range must be final when reported) or a lone block
+            dweT = E(b.rd, b.mid, dt=torch.float32)
         lib.se_mlp_bwd(dgate.data_ptr(), bs.gate.data_ptr(), bs.hr.data_ptr(), bs.hs.data_ptr(), bs.s.data_ptr(),
                        V(n + ".se.conv_reduce.weight").data_ptr(), bs.weT.data_ptr(),
                        dr.data_ptr(), ds.data_ptr(), dweT.data_ptr(), G(n + ".se.conv_reduce.weight").data_ptr(),
-                       G(n + ".se.conv_reduce.bias").data_ptr(), G(n + ".se.conv_expand.weight").data_ptr(),
+                       G(n + ".se.conv_reduce.bias").data_ptr(), None if batched else G(n + ".se.conv_expand.weight").data_ptr(),
                        G(n + ".se.conv_expand.bias").data_ptr(), B, b.mid, b.rd, s)
         lib.bn_bwd_sums_from_pool(out5.data_ptr(), bs.gate.data_ptr(), ds.data_ptr(), self._sums(st, n + "." + d_bn, "b").data_ptr(),
                                   B, Ho * Wo, b.mid, s)
@@ -623,7 +638,7 @@ class EfficientNet(nn.Module):
         for b, bs in zip(reversed(a.blocks), reversed(st.blocks)):
             dx = self._block_bwd(st, b, bs, dx)
         if st.tap_batched:      # every block's tap-major depthwise weight gradient into the gradient buffer, one launch
-            lib.dw_tap_major_batch(self._tap_bwd.data_ptr(), len(a.blocks), st.gT_all.data_ptr(), fl.grad.data_ptr(), 0, self._tap_max, s)
+            lib.dw_tap_major_batch(self._tap_bwd.data_ptr(), self._tap_n, st.gT_all.data_ptr(), fl.grad.data_ptr(), 0, self._tap_max, s)
         # ---- stem
         P0 = B * (st.Hi // 2) * (st.Wi // 2)
         dz0 = E(P0, a.stem)
