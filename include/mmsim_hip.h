@@ -205,6 +205,14 @@ int mmsim_bn_stats(const void* z, float* sums, int P, int C, float* scratch, uns
 int mmsim_bn_finalize(const float* sums, const float* gamma, const float* beta, float* mean, float* rstd, float* scale,
                       float* shift, float* run_mean, float* run_var, int C, float count, float eps, float momentum,
                       void* stream);
+/* The same finalisation ATTACHED to the reduction of the statistics: after _arm, the next partial-sum reduction into `sums` issued on
+ * this host thread (inside mmsim_gemm_bf16_bnstats, mmsim_dwtile_fwd, mmsim_pw_project_fwd, mmsim_pw_expand_fwd, mmsim_stem_fwd,
+ * mmsim_dwconv_fwd, mmsim_bn_stats) is done by a kernel that sums the slab in a fixed order (no atomics) and writes mean / rstd /
+ * scale / shift and the running statistics as well: one launch instead of two per BatchNorm.  _flush: launches mmsim_bn_finalize if
+ * nothing consumed the request; a no-op otherwise.  Results agree with the two-launch form to summation order. */
+int mmsim_bn_finalize_arm(float* sums, const float* gamma, const float* beta, float* mean, float* rstd, float* scale, float* shift,
+                          float* run_mean, float* run_var, int C, float count, float eps, float momentum);
+int mmsim_bn_finalize_flush(void* stream);
 int mmsim_bn_apply(const void* z, const float* scale, const float* shift, const void* resid, void* out, int P, int C,
                    int act_silu, void* stream);
 /* out[b,c] = mul * sum_hw act(scale*z+shift) * (other ? other : 1): SE squeeze / global pool (mul = 1/HW), SE dgate. */

@@ -114,12 +114,70 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     else out[i] += t;          // gridDim.y == 1: the only adder of this output, parts summed in a fixed order
   }
 }
+// ---- the reduction of a BatchNorm's statistics slab together with its finalisation, ONE launch, no atomics, no fences:
+// a block owns 16 channels (their sum and sum-of-squares columns), its 16 row lanes walk the slab rows 8 loads at a time, an LDS tree
+// finishes the sums in a fixed order, and the 16 channel threads write sums / mean / rstd / scale / shift / running statistics.
+// (Letting the LAST workgroup of the atomic reduction finalise -- release fence + agent-scope ticket -- was built first and measured
+// 1.3 ms/step SLOWER: each fence writes the XCD's dirty L2 lines back.  This form needs no cross-workgroup ordering at all.)
+struct BnFinDev {
+  const float* gamma; const float* beta; float* mean; float* rstd; float* scale; float* shift; float* run_mean; float* run_var;
+  int C; float count, eps, momentum;
+};
+__global__ __launch_bounds__(256) void reduce_bn_finalize_kernel(const float* __restrict__ parts, int nparts, float* sums, BnFinDev f) {
+  __shared__ float red[2][16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const bool ok = c < f.C;
+  const size_t n = (size_t)2 * f.C;
+  const float* p1 = parts + (ok ? c : 0);
+  float a1 = 0.f, a2 = 0.f;
+  for (int r0 = rl; r0 < nparts; r0 += 16 * 4) {        // four rows of each column pair in flight
+    float v1[4], v2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = min(r0 + 16 * q, nparts - 1);
+      v1[q] = p1[(size_t)r * n]; v2[q] = p1[(size_t)r * n + f.C];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float m = (r0 + 16 * q < nparts) ? 1.f : 0.f;
+      a1 += v1[q] * m; a2 += v2[q] * m;
+    }
+  }
+  red[0][rl][cl] = a1; red[1][rl][cl] = a2;
+  __syncthreads();
+  if (rl == 0 && ok) {
+    float s1 = sums[c], s2 = sums[f.C + c];            // accumulate contract of the slab reductions (pre-zeroed by the caller)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1 += red[0][r][cl]; s2 += red[1][r][cl]; }
+    sums[c] = s1; sums[f.C + c] = s2;
+    const float mu = s1 / f.count;
+    const float var = fmaxf(s2 / f.count - mu * mu, 0.f);
+    const float rs = rsqrtf(var + f.eps);
+    f.mean[c] = mu; f.rstd[c] = rs;
+    const float sc = f.gamma[c] * rs;
+    f.scale[c] = sc; f.shift[c] = f.beta[c] - mu * sc;
+    if (f.run_mean) {
+      f.run_mean[c] = (1.f - f.momentum) * f.run_mean[c] + f.momentum * mu;
+      f.run_var[c] = (1.f - f.momentum) * f.run_var[c] + f.momentum * var * (f.count / fmaxf(f.count - 1.f, 1.f));
+    }
+  }
+}
+// a BatchNorm finalisation waiting for the reduction of its statistics (per host thread; consumed by the next matching
+// mmsim_launch_reduce, or launched on its own by mmsim_bn_finalize_flush)
+struct BnFinArmed { bool armed = false; float* sums = nullptr; BnFinDev d; };
+static thread_local BnFinArmed g_bnfin;
 void mmsim_launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s);
 static void launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s) {
   mmsim_launch_reduce(parts, nparts, n, out, accumulate, s);
 }
 void mmsim_launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s) {
   if (!accumulate) (void)hipMemsetAsync(out, 0, (size_t)n * sizeof(float), s);
+  if (g_bnfin.armed && g_bnfin.sums == out && n == 2 * g_bnfin.d.C && nparts <= 4096) {
+    g_bnfin.armed = false;
+    hipLaunchKernelGGL(reduce_bn_finalize_kernel, dim3((g_bnfin.d.C + 15) / 16), dim3(256), 0, s, parts, nparts, out, g_bnfin.d);
+    return;
+  }
   int gy = nparts / 16; if (gy > 8) gy = 8; if (gy < 1) gy = 1;
   if (mmsim_deterministic()) {
     hipLaunchKernelGGL(reduce_partials_kernel<false>, dim3((n + 63) / 64, 1), dim3(256), 0, s, parts, nparts, n, out);
@@ -1217,6 +1275,29 @@ extern "C" int mmsim_bn_stats(const void* z, float* sums, int P, int C, float* s
   hipLaunchKernelGGL(bn_stats_kernel, dim3(nparts, cg_grid_y(C)), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scratch, P, C, rpb);
   launch_reduce(scratch, nparts, 2 * C, sums, 1, (hipStream_t)stream);      /* sums are pre-zeroed by the caller (header contract) */
   return mmsim_check_launch("bn_stats");
+}
+
+// Attach the finalisation of a BatchNorm to the reduction of its statistics: the NEXT partial-slab reduction into `sums` issued on
+// this host thread (inside mmsim_gemm_bf16_bnstats, mmsim_dwtile_fwd, mmsim_pw_*_fwd, mmsim_stem_fwd, ...) is done by
+// reduce_bn_finalize_kernel, which also produces mean / rstd / scale / shift / running statistics.  mmsim_bn_finalize_flush launches the
+// plain finalisation if nothing consumed the request, and is a no-op otherwise.
+extern "C" int mmsim_bn_finalize_arm(float* sums, const float* gamma, const float* beta, float* mean, float* rstd, float* scale,
+                                     float* shift, float* run_mean, float* run_var, int C, float count, float eps, float momentum) {
+  MMSIM_REQUIRE(sums && gamma && beta && mean && rstd && scale && shift && C > 0 && count > 0, "bn_finalize_arm: bad arguments");
+  g_bnfin.armed = true; g_bnfin.sums = sums;
+  BnFinDev& d = g_bnfin.d;
+  d.gamma = gamma; d.beta = beta; d.mean = mean; d.rstd = rstd; d.scale = scale; d.shift = shift; d.run_mean = run_mean; d.run_var = run_var;
+  d.C = C; d.count = count; d.eps = eps; d.momentum = momentum;
+  return 0;
+}
+extern "C" int mmsim_bn_finalize(const float* sums, const float* gamma, const float* beta, float* mean, float* rstd, float* scale,
+                                 float* shift, float* run_mean, float* run_var, int C, float count, float eps, float momentum, void* stream);
+extern "C" int mmsim_bn_finalize_flush(void* stream) {
+  if (!g_bnfin.armed) return 0;
+  g_bnfin.armed = false;
+  const BnFinDev& d = g_bnfin.d;
+  return mmsim_bn_finalize(g_bnfin.sums, d.gamma, d.beta, d.mean, d.rstd, d.scale, d.shift, d.run_mean, d.run_var, d.C, d.count, d.eps,
+                           d.momentum, stream);
 }
 
 extern "C" int mmsim_bn_finalize(const float* sums, const float* gamma, const float* beta, float* mean, float* rstd, float* scale,

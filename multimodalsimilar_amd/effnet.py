@@ -78,6 +78,8 @@ _PW_FUSED = os.environ.get("MMSIM_PW_FUSED", "1") != "0"
 _PW_PROJECT = os.environ.get("MMSIM_PW_PROJECT", "1") != "0"
 # MMSIM_S2_XF=0: stride-2 blocks store a1 = silu(bn1(z1)) (a bn_apply pass) instead of re-forming it in the depthwise kernels
 _S2_XF = os.environ.get("MMSIM_S2_XF", "1") != "0"
+# MMSIM_BN_FUSED_FINALIZE=0: BatchNorm statistics reduced with atomics and finalised by a second launch (A/B switch)
+_BN_FUSED_FINALIZE = os.environ.get("MMSIM_BN_FUSED_FINALIZE", "1") != "0"
 
 class _Holder(nn.Module):
     pass
@@ -274,9 +276,25 @@ class EfficientNet(nn.Module):
         o, c = self._bn_off[name], dict(self._bn_list)[name]
         return st.bnstat[i, o:o + c]
 
+    def _bn_arm(self, st, name, sums, count):
+        """Training mode: attach this BatchNorm's finalisation to the reduction of its statistics inside the producer that is about to
+        run (mmsim_bn_finalize_arm); _bn_finalize after the producer then only flushes (a launch only if the producer did not reduce)."""
+        if not self.training or not _BN_FUSED_FINALIZE:
+            return
+        fl = self._flat
+        o, c = self._bn_off[name], sums.numel() // 2
+        lib.bn_finalize_arm(sums.data_ptr(), fl.view(name + ".weight").data_ptr(), fl.view(name + ".bias").data_ptr(),
+                            self._bnp(st, name, 0).data_ptr(), self._bnp(st, name, 1).data_ptr(),
+                            self._bnp(st, name, 2).data_ptr(), self._bnp(st, name, 3).data_ptr(),
+                            self._run[o:o + c].data_ptr(), self._run[self._bn_total + o:self._bn_total + o + c].data_ptr(),
+                            c, float(count), BN_EPS, BN_MOMENTUM)
+
     def _bn_finalize(self, st, name, sums, count):
         fl, s = self._flat, ops._stream()
         o, c = self._bn_off[name], sums.numel() // 2
+        if self.training and _BN_FUSED_FINALIZE:
+            lib.bn_finalize_flush(s)
+            return
         if not self.training:
             # eval: normalise with the running statistics (nn.BatchNorm2d.eval()); per-channel vectors only
             rm, rv = self._run[o:o + c], self._run[self._bn_total + o:self._bn_total + o + c]
@@ -309,6 +327,7 @@ class EfficientNet(nn.Module):
         if b.type == "ir":
             bs.z1 = E(P_in, b.mid)
             sm = self._sums(st, n + "." + e_bn, "f")
+            self._bn_arm(st, n + "." + e_bn, sm, P_in)
             w1 = SV(n + ".conv_pw.weight", (b.mid, b.cin))
             if _PW_PROJECT and lib.pw_expand_fwd_eligible(P_in, b.mid, b.cin):
                 lib.pw_expand_fwd(cur.data_ptr(), w1.data_ptr(), bs.z1.data_ptr(), sm.data_ptr(), P_in, b.mid, b.cin, *self._scr(), s)
@@ -332,6 +351,7 @@ class EfficientNet(nn.Module):
         bs.wT = st.wT_all[o:o + b.k * b.k * b.mid].view(b.k * b.k, b.mid)
         bs.z2 = E(P_out, b.mid)
         sm = self._sums(st, n + "." + d_bn, "f")
+        self._bn_arm(st, n + "." + d_bn, sm, P_out)
         if not _DWTILE:
             lib.dwconv_fwd(bs.a1.data_ptr(), bs.wT.data_ptr(), bs.z2.data_ptr(), sm.data_ptr(), B, H, W, b.mid, b.k, b.stride, *self._scr(), s)
         elif bs.a1 is None:
@@ -363,6 +383,7 @@ class EfficientNet(nn.Module):
         bs.z3 = E(P_out, b.cout)
         w3 = SV(pw + ".weight", (b.cout, b.mid))
         sm = self._sums(st, n + "." + p_bn, "f")
+        self._bn_arm(st, n + "." + p_bn, sm, P_out)
         if bs.a2 is not None and _PW_PROJECT and lib.pw_project_fwd_eligible(P_out, Ho * Wo, b.mid, b.cout):
             # early stages: one streaming pass over a2 (gate applied on the way into LDS), W3 resident in LDS, statistics in registers
             lib.pw_project_fwd(bs.a2.data_ptr(), bs.gate.data_ptr(), w3.data_ptr(), bs.z3.data_ptr(), sm.data_ptr(), P_out, Ho * Wo,
@@ -402,6 +423,7 @@ class EfficientNet(nn.Module):
         H, W = Hi // 2, Wi // 2
         P = B * H * W
         st.z0 = E(P, a.stem)
+        self._bn_arm(st, "bn1", self._sums(st, "bn1", "f"), P)
         lib.stem_fwd(x.data_ptr(), V("conv_stem.weight").data_ptr(), st.z0.data_ptr(), self._sums(st, "bn1", "f").data_ptr(),
                      B, Hi, Wi, a.stem, *self._scr(), s)
         self._bn_finalize(st, "bn1", self._sums(st, "bn1", "f"), P)
@@ -417,6 +439,7 @@ class EfficientNet(nn.Module):
         st.x_last, st.Hh, st.Wh = cur, H, W
         st.zh = E(P, a.head)
         sm = self._sums(st, "bn2", "f")
+        self._bn_arm(st, "bn2", sm, P)
         wh = SV("conv_head.weight", (a.head, a.last))
         lib.gemm_bf16_bnstats(0, P, a.head, a.last, cur.data_ptr(), a.last, wh.data_ptr(), a.last, st.zh.data_ptr(), a.head,
                               None, None, None, 1, sm.data_ptr(), *self._scr(), s)
