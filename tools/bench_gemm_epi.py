@@ -1,5 +1,5 @@
-"""The text tower's forward / data-gradient products with their real epilogues (run once per MMSIM_GEMM_MIXED setting): time, TFLOP/s
-and max error against torch."""
+"""The text tower's forward / data-gradient products with their real epilogues: time, TFLOP/s and max error against torch (used to
+A/B kernel variants selected by an environment switch or by MMSIM_LIB: run once per setting)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -38,4 +38,4 @@ for name, N, K, epi, kmaj in (("qkv_fwd", 3072, 1024, ops.EPI_NONE, True), ("o_f
     err = ((y[rows].float() - ref).abs().max() / ref.abs().max()).item()
     t = bench(lambda: ops.gemm(x, w, y, **kw)); tot += t
     out.append(f"{name} {t*1e3:.1f}us {2.0*M*N*K/t/1e9:.0f}TF err {err:.1e}")
-print("MIXED=" + os.environ.get("MMSIM_GEMM_MIXED", "1"), " | ".join(out), f"| sum {tot*1e3:.0f}us", flush=True)
+print(" | ".join(out), f"| sum {tot*1e3:.0f}us", flush=True)
