@@ -114,6 +114,42 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     else out[i] += t;          // gridDim.y == 1: the only adder of this output, parts summed in a fixed order
   }
 }
+// Two slab reductions that share their row count in one launch (the depthwise backward's BatchNorm sums and tap-major weight
+// gradient): blockIdx.x < gx_a works on job a, the rest on job b; otherwise reduce_partials_kernel.
+template <bool ATOMIC>
+__global__ __launch_bounds__(256) void reduce_partials2_kernel(const float* __restrict__ pa, int na, float* oa, const float* __restrict__ pb,
+                                                               int nb, float* ob, int nparts, int gx_a) {
+  __shared__ float red[4][64];
+  const bool second = (int)blockIdx.x >= gx_a;
+  const float* parts = second ? pb : pa;
+  const int n = second ? nb : na;
+  float* out = second ? ob : oa;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = ((int)blockIdx.x - (second ? gx_a : 0)) * 64 + lane;
+  float a0 = 0.f, a1 = 0.f;
+  if (i < n) {
+    const int step = gridDim.y * 4;
+    int p = blockIdx.y * 4 + wv;
+    for (; p + step < nparts; p += 2 * step) { a0 += parts[(size_t)p * n + i]; a1 += parts[(size_t)(p + step) * n + i]; }
+    if (p < nparts) a0 += parts[(size_t)p * n + i];
+  }
+  red[wv][lane] = a0 + a1;
+  __syncthreads();
+  if (wv == 0 && i < n) {
+    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (ATOMIC) atomicAdd(out + i, t);
+    else out[i] += t;
+  }
+}
+void mmsim_launch_reduce2(const float* pa, int na, float* oa, const float* pb, int nb, float* ob, int nparts, hipStream_t s) {
+  const int gx_a = (na + 63) / 64, gx_b = (nb + 63) / 64;
+  int gy = nparts / 16; if (gy > 8) gy = 8; if (gy < 1) gy = 1;
+  if (mmsim_deterministic())
+    hipLaunchKernelGGL(reduce_partials2_kernel<false>, dim3(gx_a + gx_b, 1), dim3(256), 0, s, pa, na, oa, pb, nb, ob, nparts, gx_a);
+  else
+    hipLaunchKernelGGL(reduce_partials2_kernel<true>, dim3(gx_a + gx_b, gy), dim3(256), 0, s, pa, na, oa, pb, nb, ob, nparts, gx_a);
+}
+
 // ---- the reduction of a BatchNorm's statistics slab together with its finalisation, ONE launch, no atomics, no fences:
 // a block owns 16 channels (their sum and sum-of-squares columns), its 16 row lanes walk the slab rows 8 loads at a time, an LDS tree
 // finishes the sums in a fixed order, and the 16 channel threads write sums / mean / rstd / scale / shift / running statistics.

@@ -520,6 +520,7 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
 
 // ================================================================= host side
 void mmsim_launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s);   // conv.hip
+void mmsim_launch_reduce2(const float* pa, int na, float* oa, const float* pb, int nb, float* ob, int nparts, hipStream_t s);
 
 
 // Channel units per block: a divisor of the unit count near `target` octets (8 = 128 B per pixel) when there is one, so that
@@ -641,8 +642,8 @@ extern "C" int mmsim_dwtile_bwd(const void* dy, const void* z2, const float* sca
   if (K == 3) { if (plain) DWT_B(3, true); else DWT_B(3, false); }
   else { if (plain) DWT_B(5, true); else DWT_B(5, false); }
 #undef DWT_B
-  if (!plain) mmsim_launch_reduce(p.parts_bn, grid.x, 2 * C, sums1, 1, s);
-  mmsim_launch_reduce(p.parts_w, grid.x, K * K * C, g_tap_major, 1, s);
+  if (!plain) mmsim_launch_reduce2(p.parts_bn, 2 * C, sums1, p.parts_w, K * K * C, g_tap_major, grid.x, s);      // both slabs, one launch
+  else mmsim_launch_reduce(p.parts_w, grid.x, K * K * C, g_tap_major, 1, s);
   return mmsim_check_launch("dwtile_bwd");
 }
 
