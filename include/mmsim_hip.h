@@ -314,6 +314,15 @@ int mmsim_pw_expand_fwd_eligible(int P, int mid, int cin);
 int mmsim_pw_expand_fwd(const void* x, const void* w1_bf16, void* z1, float* sums, int P, int mid, int cin, float* scratch,
                         unsigned long long scratch_floats, void* stream);
 
+/* The two streaming projection kernels with the operand formed on the fly: `z2` is the pre-BatchNorm depthwise output and the operand
+ * is silu(xf_scale z2 + xf_shift) * gate -- the activated tensor a2 is then never stored (forward) nor read (backward). */
+int mmsim_pw_project_fwd_xf(const void* z2, const float* xf_scale, const float* xf_shift, const float* gate, const void* w3_bf16,
+                            void* z3, float* sums, int P, int HW, int mid, int cout, float* scratch,
+                            unsigned long long scratch_floats, void* stream);
+int mmsim_pw_project_bwd_xf(const void* dz3, const void* z2, const float* xf_scale, const float* xf_shift, const float* gate,
+                            const void* w3_bf16, void* da, float* dw3, int P, int HW, int mid, int cout, float* scratch,
+                            unsigned long long scratch_floats, void* stream);
+
 /* Backward of the same conv as one streaming pass (autograd of conv_pwl / conv_pw after bn + SiLU + SE):
  *   da[P,mid] (bf16) = dz3[P,cout] W3[cout,mid]            -- the gradient w.r.t. the GATED activation a2 * gate
  *   dw3[cout,mid] (fp32) += dz3^T (a2 * gate[P / HW])

@@ -822,6 +822,7 @@ static int launch_pw_expand_bwd(PwBwd p, float* dw1, hipStream_t s, float* scrat
 // plain 16-byte fragment reads.  Statistics stay in registers until the block ends (slab + mmsim_launch_reduce).
 struct PwPrj {
   const bf16* a2; const float* gate; const bf16* w3; bf16* z3; float* parts;
+  const float* xsc; const float* xsh;      // non-NULL: `a2` is the pre-BatchNorm tensor z2 and the operand is silu(xsc z2 + xsh) * gate
   int P, HW, B, mid, cout, nstrips, per_block, KS;
   FastDiv dhw;
 };
@@ -840,9 +841,12 @@ __global__ __launch_bounds__(256) void pw_project_fwd_kernel(PwPrj p) {
   char* zimg = smem;                                      // [BM][KS*32] bf16: gated a2 of the strip, k-major
   char* wimg = zimg + BM * ZP;                            // [COUT_T*16][KS*32] bf16: W3 (rows = cout, zero rows past cout)
   float* grow = reinterpret_cast<float*>(wimg + COUT_T * 16 * ZP);      // [2][mid]: gate rows of image cur_b, cur_b + 1
-  float* red = grow + 2 * p.mid;                          // [4 waves][2][COUT_T*16]
+  float* xs = grow + 2 * p.mid;                           // [2][mid]: BatchNorm scale | shift of the operand transform (if any)
+  float* red = xs + 2 * p.mid;                            // [4 waves][2][COUT_T*16]
   for (int i = tid; i < (BM * ZP + COUT_T * 16 * ZP) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
   for (int i = tid; i < 4 * 2 * COUT_T * 16; i += 256) red[i] = 0.f;
+  if (p.xsc)
+    for (int i = tid; i < p.mid; i += 256) { xs[i] = p.xsc[i]; xs[p.mid + i] = p.xsh[i]; }
   __syncthreads();
   for (int i = tid; i < p.cout * G; i += 256) {
     const int r = i / G, c = i - r * G;
@@ -887,8 +891,14 @@ __global__ __launch_bounds__(256) void pw_project_fwd_kernel(PwPrj p) {
         const float* gr = grow + (pix >= split ? p.mid : 0) + un * 8;
         const bf8 a = __builtin_bit_cast(bf8, va[i]);
         bf8 o;
+        if (p.xsc) {      // launch-uniform: the activation is formed here, a2 is never stored
+          const float* cs = xs + un * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(a[e]) * gr[e]);
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(silu_f(bf2f(a[e]) * cs[e] + cs[p.mid + e]) * gr[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(a[e]) * gr[e]);
+        }
         *reinterpret_cast<bf8*>(zimg + pix * ZP + un * 16) = o;
       }
     }
@@ -952,7 +962,7 @@ static int launch_pw_project_fwd(PwPrj p, float* sums, hipStream_t s, float* scr
   p.nstrips = p.P / BM;
   p.KS = (p.mid + 31) / 32;
   const int ZP = p.KS * 64 + 16;
-  const size_t lds = (size_t)BM * ZP + (size_t)COUT_T * 16 * ZP + (size_t)2 * p.mid * 4 + (size_t)4 * 2 * COUT_T * 16 * 4;
+  const size_t lds = (size_t)BM * ZP + (size_t)COUT_T * 16 * ZP + (size_t)4 * p.mid * 4 + (size_t)4 * 2 * COUT_T * 16 * 4;
   MMSIM_REQUIRE(lds <= 100 * 1024, "pw_project_fwd: LDS images too large");
   MMSIM_REQUIRE(BM * (p.mid >> 3) <= 256 * NCH, "pw_project_fwd: strip too wide for the staging registers");
   int grid = p.nstrips < 1024 ? p.nstrips : 1024;
@@ -982,12 +992,27 @@ static int pw_project_variant(int P, int HW, int mid, int cout) {
 }
 extern "C" int mmsim_pw_project_fwd_eligible(int P, int HW, int mid, int cout) { return pw_project_variant(P, HW, mid, cout) != 0; }
 
+static int pw_project_fwd_impl(const void* a2, const float* xf_scale, const float* xf_shift, const float* gate, const void* w3_bf16,
+                               void* z3, float* sums, int P, int HW, int mid, int cout, float* scratch,
+                               unsigned long long scratch_floats, void* stream);
 extern "C" int mmsim_pw_project_fwd(const void* a2, const float* gate, const void* w3_bf16, void* z3, float* sums, int P, int HW,
                                     int mid, int cout, float* scratch, unsigned long long scratch_floats, void* stream) {
+  return pw_project_fwd_impl(a2, nullptr, nullptr, gate, w3_bf16, z3, sums, P, HW, mid, cout, scratch, scratch_floats, stream);
+}
+extern "C" int mmsim_pw_project_fwd_xf(const void* z2, const float* xf_scale, const float* xf_shift, const float* gate, const void* w3_bf16,
+                                       void* z3, float* sums, int P, int HW, int mid, int cout, float* scratch,
+                                       unsigned long long scratch_floats, void* stream) {
+  MMSIM_REQUIRE(xf_scale && xf_shift, "pw_project_fwd_xf: scale and shift required");
+  return pw_project_fwd_impl(z2, xf_scale, xf_shift, gate, w3_bf16, z3, sums, P, HW, mid, cout, scratch, scratch_floats, stream);
+}
+static int pw_project_fwd_impl(const void* a2, const float* xf_scale, const float* xf_shift, const float* gate, const void* w3_bf16,
+                               void* z3, float* sums, int P, int HW, int mid, int cout, float* scratch,
+                               unsigned long long scratch_floats, void* stream) {
   MMSIM_REQUIRE(a2 && gate && w3_bf16 && z3 && sums && scratch, "pw_project_fwd: null operand");
   const int v = pw_project_variant(P, HW, mid, cout);
   MMSIM_REQUIRE(v != 0, "pw_project_fwd: shape not eligible (see mmsim_pw_project_fwd_eligible)");
   PwPrj p;
+  p.xsc = xf_scale; p.xsh = xf_shift;
   p.a2 = (const bf16*)a2; p.gate = gate; p.w3 = (const bf16*)w3_bf16; p.z3 = (bf16*)z3;
   p.P = P; p.HW = HW; p.B = P / HW; p.mid = mid; p.cout = cout; p.dhw = make_fastdiv((unsigned)HW);
   if (v == 1) return launch_pw_project_fwd<256, 2, 6>(p, sums, (hipStream_t)stream, scratch, scratch_floats);
@@ -1131,6 +1156,7 @@ extern "C" int mmsim_pw_expand_fwd(const void* x, const void* w1_bf16, void* z1,
 // transposing LDS reads and stays in registers for the block's lifetime (slab + mmsim_launch_reduce).
 struct PwPrjBwd {
   const bf16* dz3; const bf16* a2; const float* gate; const bf16* w3; bf16* da; float* parts;
+  const float* xsc; const float* xsh;      // as in PwPrj
   int P, HW, B, mid, cout, nstrips, per_block, KS;
   FastDiv dhw;
 };
@@ -1150,7 +1176,10 @@ __global__ __launch_bounds__(256) void pw_project_bwd_kernel(PwPrjBwd p) {
   char* ximg = oimg + BM * ZP;                            // [BM][COUT_T*16]  dz3 (rows = pixels)
   char* wimg = ximg + BM * XP;                            // [COUT_T*16][KS*32]  W3 (rows = cout)
   float* grow = reinterpret_cast<float*>(wimg + COUT_T * 16 * ZP);      // [2][mid]
+  float* xs = grow + 2 * p.mid;                           // [2][mid]: scale | shift of the operand transform (if any)
   for (int i = tid; i < (2 * BM * ZP + BM * XP + COUT_T * 16 * ZP) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  if (p.xsc)
+    for (int i = tid; i < p.mid; i += 256) { xs[i] = p.xsc[i]; xs[p.mid + i] = p.xsh[i]; }
   __syncthreads();
   for (int i = tid; i < p.cout * G; i += 256) {
     const int r = i / G, c = i - r * G;
@@ -1192,8 +1221,14 @@ __global__ __launch_bounds__(256) void pw_project_bwd_kernel(PwPrjBwd p) {
         const float* gr = grow + (pix >= split ? p.mid : 0) + un * 8;
         const bf8 a = __builtin_bit_cast(bf8, va[i]);
         bf8 o;
+        if (p.xsc) {
+          const float* cs = xs + un * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(a[e]) * gr[e]);
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(silu_f(bf2f(a[e]) * cs[e] + cs[p.mid + e]) * gr[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(a[e]) * gr[e]);
+        }
         *reinterpret_cast<bf8*>(zimg + pix * ZP + un * 16) = o;
       }
     }
@@ -1260,7 +1295,7 @@ static int launch_pw_project_bwd(PwPrjBwd p, float* dw3, hipStream_t s, float* s
   p.nstrips = p.P / BM;
   p.KS = (p.mid + 31) / 32;
   const int ZP = p.KS * 64 + 16, XP = COUT_T * 32 + 16;
-  const size_t lds = (size_t)2 * BM * ZP + (size_t)BM * XP + (size_t)COUT_T * 16 * ZP + (size_t)2 * p.mid * 4;
+  const size_t lds = (size_t)2 * BM * ZP + (size_t)BM * XP + (size_t)COUT_T * 16 * ZP + (size_t)4 * p.mid * 4;
   MMSIM_REQUIRE(lds <= 100 * 1024, "pw_project_bwd: LDS images too large");
   MMSIM_REQUIRE(BM * (p.mid >> 3) <= 256 * NCH && BM * (p.cout >> 3) <= 256 * NCX, "pw_project_bwd: strip too wide for the staging registers");
   MMSIM_REQUIRE(COUT_T * ((p.mid + 15) / 16) <= 4 * MAXW, "pw_project_bwd: weight gradient does not fit the accumulators");
@@ -1290,12 +1325,27 @@ static int pw_project_bwd_variant(int P, int HW, int mid, int cout) {
 }
 extern "C" int mmsim_pw_project_bwd_eligible(int P, int HW, int mid, int cout) { return pw_project_bwd_variant(P, HW, mid, cout) != 0; }
 
+static int pw_project_bwd_impl(const void* dz3, const void* a2, const float* xf_scale, const float* xf_shift, const float* gate,
+                               const void* w3_bf16, void* da, float* dw3, int P, int HW, int mid, int cout, float* scratch,
+                               unsigned long long scratch_floats, void* stream);
 extern "C" int mmsim_pw_project_bwd(const void* dz3, const void* a2, const float* gate, const void* w3_bf16, void* da, float* dw3,
                                     int P, int HW, int mid, int cout, float* scratch, unsigned long long scratch_floats, void* stream) {
+  return pw_project_bwd_impl(dz3, a2, nullptr, nullptr, gate, w3_bf16, da, dw3, P, HW, mid, cout, scratch, scratch_floats, stream);
+}
+extern "C" int mmsim_pw_project_bwd_xf(const void* dz3, const void* z2, const float* xf_scale, const float* xf_shift, const float* gate,
+                                       const void* w3_bf16, void* da, float* dw3, int P, int HW, int mid, int cout, float* scratch,
+                                       unsigned long long scratch_floats, void* stream) {
+  MMSIM_REQUIRE(xf_scale && xf_shift, "pw_project_bwd_xf: scale and shift required");
+  return pw_project_bwd_impl(dz3, z2, xf_scale, xf_shift, gate, w3_bf16, da, dw3, P, HW, mid, cout, scratch, scratch_floats, stream);
+}
+static int pw_project_bwd_impl(const void* dz3, const void* a2, const float* xf_scale, const float* xf_shift, const float* gate,
+                               const void* w3_bf16, void* da, float* dw3, int P, int HW, int mid, int cout, float* scratch,
+                               unsigned long long scratch_floats, void* stream) {
   MMSIM_REQUIRE(dz3 && a2 && gate && w3_bf16 && da && dw3 && scratch, "pw_project_bwd: null operand");
   const int v = pw_project_bwd_variant(P, HW, mid, cout);
   MMSIM_REQUIRE(v != 0, "pw_project_bwd: shape not eligible (see mmsim_pw_project_bwd_eligible)");
   PwPrjBwd p;
+  p.xsc = xf_scale; p.xsh = xf_shift;
   p.dz3 = (const bf16*)dz3; p.a2 = (const bf16*)a2; p.gate = gate; p.w3 = (const bf16*)w3_bf16; p.da = (bf16*)da;
   p.P = P; p.HW = HW; p.B = P / HW; p.mid = mid; p.cout = cout; p.dhw = make_fastdiv((unsigned)HW);
   if (v == 1) return launch_pw_project_bwd<128, 2, 3, 2, 2>(p, dw3, (hipStream_t)stream, scratch, scratch_floats);

@@ -69,6 +69,8 @@ def count_macs(model_name, res=224):
 # MMSIM_KEEP_A2=0: do not keep the activated depthwise output; the projection conv then applies BN + SiLU + gate while it
 # stages its operand (saves one [pixels, mid] bf16 tensor per block, costs ~2 ms/step at cfg4: those products become VALU-bound)
 _KEEP_A2 = os.environ.get("MMSIM_KEEP_A2", "1") != "0"
+# MMSIM_A2_FLY=0: keep a2 also in the blocks whose projection conv runs the streaming kernels (A/B switch)
+_A2_FLY = os.environ.get("MMSIM_A2_FLY", "1") != "0"
 # MMSIM_DWTILE=0: the round-1 depthwise kernels (rows straight from global memory; separate bn_apply / bn_bwd_apply passes)
 # instead of the LDS-tiled ones of csrc/mbconv.hip (A/B switch)
 _DWTILE = os.environ.get("MMSIM_DWTILE", "1") != "0"
@@ -363,7 +365,11 @@ class EfficientNet(nn.Module):
         self._bn_finalize(st, n + "." + d_bn, sm, P_out)
         sc2, sh2 = self._bnp(st, n + "." + d_bn, 2), self._bnp(st, n + "." + d_bn, 3)
         bs.s = E(B, b.mid, dt=torch.float32)
-        if _KEEP_A2:      # the SE squeeze also keeps a2 = silu(bn(z2)): the projection conv's operand is then a2 * gate
+        pw = n + (".conv_pw" if b.type == "ds" else ".conv_pwl")
+        # early stages: both projection kernels stream and can form silu(bn(z2)) * gate themselves -- a2 is then not stored at all
+        bs.a2_fly = (_A2_FLY and _PW_PROJECT and lib.pw_project_fwd_eligible(P_out, Ho * Wo, b.mid, b.cout)
+                     and lib.pw_project_bwd_eligible(P_out, Ho * Wo, b.mid, b.cout))
+        if _KEEP_A2 and not bs.a2_fly:      # the SE squeeze also keeps a2 = silu(bn(z2)): the projection conv's operand is then a2 * gate
             bs.a2 = E(P_out, b.mid)
             lib.pool_bn_act_store(bs.z2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), bs.a2.data_ptr(), bs.s.data_ptr(), B, Ho * Wo,
                                   b.mid, 1.0 / (Ho * Wo), s)
@@ -384,7 +390,10 @@ class EfficientNet(nn.Module):
         w3 = SV(pw + ".weight", (b.cout, b.mid))
         sm = self._sums(st, n + "." + p_bn, "f")
         self._bn_arm(st, n + "." + p_bn, sm, P_out)
-        if bs.a2 is not None and _PW_PROJECT and lib.pw_project_fwd_eligible(P_out, Ho * Wo, b.mid, b.cout):
+        if bs.a2_fly:
+            lib.pw_project_fwd_xf(bs.z2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), bs.gate.data_ptr(), w3.data_ptr(), bs.z3.data_ptr(),
+                                  sm.data_ptr(), P_out, Ho * Wo, b.mid, b.cout, *self._scr(), s)
+        elif bs.a2 is not None and _PW_PROJECT and lib.pw_project_fwd_eligible(P_out, Ho * Wo, b.mid, b.cout):
             # early stages: one streaming pass over a2 (gate applied on the way into LDS), W3 resident in LDS, statistics in registers
             lib.pw_project_fwd(bs.a2.data_ptr(), bs.gate.data_ptr(), w3.data_ptr(), bs.z3.data_ptr(), sm.data_ptr(), P_out, Ho * Wo,
                                b.mid, b.cout, *self._scr(), s)
@@ -518,7 +527,11 @@ class EfficientNet(nn.Module):
         sc2, sh2 = self._bnp(st, n + "." + d_bn, 2), self._bnp(st, n + "." + d_bn, 3)
         gw3 = G(pw + ".weight").view(b.cout, b.mid)
         da2g = E(P_out, b.mid)
-        if getattr(bs, "a2", None) is not None and _PW_PROJECT and lib.pw_project_bwd_eligible(P_out, Ho * Wo, b.mid, b.cout):
+        if getattr(bs, "a2_fly", False):
+            lib.pw_project_bwd_xf(dz3.data_ptr(), bs.z2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), bs.gate.data_ptr(),
+                                  SV(pw + ".weight", (b.cout, b.mid)).data_ptr(), da2g.data_ptr(), gw3.data_ptr(), P_out, Ho * Wo,
+                                  b.mid, b.cout, *self._scr(), s)
+        elif getattr(bs, "a2", None) is not None and _PW_PROJECT and lib.pw_project_bwd_eligible(P_out, Ho * Wo, b.mid, b.cout):
             # early stages: dW3 and d(a2*gate) out of one streaming pass over a2
             lib.pw_project_bwd(dz3.data_ptr(), bs.a2.data_ptr(), bs.gate.data_ptr(), SV(pw + ".weight", (b.cout, b.mid)).data_ptr(),
                                da2g.data_ptr(), gw3.data_ptr(), P_out, Ho * Wo, b.mid, b.cout, *self._scr(), s)

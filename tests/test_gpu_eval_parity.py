@@ -167,4 +167,9 @@ def test_two_tower_eval_embedding_and_forward_test_match_the_oracle():
     assert ei < 1.35 * d0 + 0.005                                      # image half: the oracle's own bf16-storage floor (see header)
     cos_emu = arcface_ref.arcface_forward_test(arcface_ref.glue_concat(e_img_emu, e_txt), model.classifier.weight.detach().cpu())
     assert (cos.cpu() - cos_ref).abs().max() < 1.35 * (cos_emu - cos_ref).abs().max() + 0.005
-    assert (cos.argmax(1).cpu() == cos_ref.argmax(1)).float().mean() >= 0.9
+    # predictions: wherever the reference's top-1 margin exceeds twice the measured cosine error the argmax must agree (random-weight
+    # classes are near-tied: a fixed agreement rate over ten rows is a coin flip on the ties, not a property of the kernels)
+    err = (cos.cpu() - cos_ref).abs().max()
+    top2 = cos_ref.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2 * err
+    assert (cos.argmax(1).cpu()[clear] == cos_ref.argmax(1)[clear]).all()

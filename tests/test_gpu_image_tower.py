@@ -643,3 +643,35 @@ def test_streaming_expansion_forward_equals_the_gemm_form(P, mid, cin):
     assert torch.equal(z1, z1g) or relerr(z1, z1g) < 4e-3                 # one 32-deep MFMA step either way: usually bit-equal
     assert relerr(sums, sums_g) < 1e-3
     assert not lib.pw_expand_fwd_eligible(P, 336, 56) and not lib.pw_expand_fwd_eligible(P + 8, mid, cin)
+
+
+@pytest.mark.parametrize("B,HW,mid,cout", [(3, 256, 48, 24), (5, 64, 192, 32), (4, 96, 144, 24)])
+def test_streaming_projection_with_the_activation_formed_on_the_fly(B, HW, mid, cout):
+    """mmsim_pw_project_fwd_xf / _bwd_xf: the operand silu(scale z2 + shift) * gate is formed while the strip is staged (a2 never
+    stored).  Against fp32 torch and against the stored-a2 kernels fed with a2 = bf16(silu(scale z2 + shift))."""
+    lib, s = _lib()
+    P = B * HW
+    z2 = rnd(P, mid, seed=1).bfloat16()
+    scale, shift = 1 + 0.1 * rnd(mid, seed=6), 0.1 * rnd(mid, seed=7)
+    gate = torch.sigmoid(rnd(B, mid, seed=2))
+    w3 = rnd(cout, mid, seed=3, scale=0.2).bfloat16()
+    act = F.silu(z2.float() * scale + shift)
+    ag = (act.view(B, HW, mid) * gate.unsqueeze(1)).reshape(P, mid)
+    z3 = torch.empty(P, cout, dtype=torch.bfloat16, device=DEV)
+    sums = torch.zeros(2 * cout, device=DEV)
+    lib.pw_project_fwd_xf(z2.data_ptr(), scale.data_ptr(), shift.data_ptr(), gate.data_ptr(), w3.data_ptr(), z3.data_ptr(),
+                          sums.data_ptr(), P, HW, mid, cout, *scr(), s)
+    assert relerr(z3, ag @ w3.float().t()) < 1e-2
+    assert relerr(sums[:cout], z3.float().sum(0)) < 1e-4
+    a2 = act.bfloat16()
+    z3s = torch.empty_like(z3)
+    sums_s = torch.zeros_like(sums)
+    lib.pw_project_fwd(a2.data_ptr(), gate.data_ptr(), w3.data_ptr(), z3s.data_ptr(), sums_s.data_ptr(), P, HW, mid, cout, *scr(), s)
+    assert relerr(z3, z3s) < 6e-3                      # one rounding (fp32 activation x gate) instead of two
+    dz3 = rnd(P, cout, seed=4).bfloat16()
+    da = torch.empty(P, mid, dtype=torch.bfloat16, device=DEV)
+    dw = torch.zeros(cout, mid, device=DEV)
+    lib.pw_project_bwd_xf(dz3.data_ptr(), z2.data_ptr(), scale.data_ptr(), shift.data_ptr(), gate.data_ptr(), w3.data_ptr(),
+                          da.data_ptr(), dw.data_ptr(), P, HW, mid, cout, *scr(), s)
+    assert relerr(da, dz3.float() @ w3.float()) < 1e-2
+    assert relerr(dw, dz3.float().t() @ ag) < 5e-3
