@@ -59,7 +59,7 @@ class CvClassifier(nn.Module):
             self.fc = nn.Linear(in_features, fc_dim)
             self.bn = nn.BatchNorm1d(fc_dim)
             self._flat = FlatBuffer([("fc.weight", (fc_dim, in_features)), ("fc.bias", (fc_dim,)),
-                                     ("bn.weight", (fc_dim,)), ("bn.bias", (fc_dim,))], device="cpu")
+                                     ("bn.weight", (fc_dim,)), ("bn.bias", (fc_dim,))], device="cpu", f16_shadow=True)
             with torch.no_grad():
                 for n, p in self._top_params():
                     self._flat.view(n).copy_(p)
@@ -133,10 +133,11 @@ class _CvTopFn(torch.autograd.Function):
         if train:
             mod._step_seed += 1
         seed = (mod._step_seed * 0x9E3779B97F4A7C15 + 0xC0FFEE) & 0xFFFFFFFFFFFFFFFF
-        xb = torch.empty(B, Cin, dtype=torch.bfloat16, device=pooled.device)
+        # the image tower's forward tensors are fp16 (effnet.py): the pooled features and the fc weight enter the MFMAs as fp16
+        xb = torch.empty(B, Cin, dtype=torch.float16, device=pooled.device)
         lib.dropout_cast(pooled.data_ptr(), xb.data_ptr(), B * Cin, p, seed, 1, s)
         y = torch.empty(B, fc_dim, dtype=torch.float32, device=pooled.device)
-        ops.gemm(xb, fl.sview("fc.weight"), y, bias=fl.view("fc.bias"))
+        ops.gemm(xb, fl.sview16("fc.weight"), y, bias=fl.view("fc.bias"))
         out = torch.empty_like(y)
         mean = torch.empty(fc_dim, dtype=torch.float32, device=y.device)
         rstd = torch.empty_like(mean)

@@ -73,10 +73,21 @@ int mmsim_gemm_bf16_wgrad_colsum(int M, int N, int K, const void* A, int lda, co
  * staged: x -> silu(xf_scale[c] x + xf_shift[c]) * xf_gate[pixel / xf_hw, c]  (gate may be NULL); with xf_scale = xf_shift =
  * NULL the operand is already activated (mmsim_pool_bn_act_store) and only x -> x * gate remains.
  *   xf_operand 1 (forward): C[P,Cout] = xf(A)[P,Cin] B[Cout,Cin]^T;  2 (wgrad): C[Cout,Cin] (+)= A[P,Cout]^T xf(B)[P,Cin].
- * Replaces timm's conv_pwl / conv_pw after bn+act+se inside the MBConv blocks under cv_classifier.py:49. */
+ * Replaces timm's conv_pwl / conv_pw after bn+act+se inside the MBConv blocks under cv_classifier.py:49.
+ * Element types (image-tower contract, see the EfficientNet section): xf_operand 1 -- A (activation), B (weight shadow) and a
+ * non-f32 C are fp16, the MFMAs run on fp16; xf_operand 2 -- A = the bf16 gradient, B = the fp16 activation (converted to bf16
+ * while it is staged), C f32. */
 int mmsim_gemm_bf16_xf(int xf_operand, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                        int ldc, int c_is_f32, const float* xf_scale, const float* xf_shift, const float* xf_gate,
                        int xf_hw, int split_k, int accumulate, void* stream);
+
+/* mmsim_gemm_bf16 with an explicit element format: fmt 0 = bf16 (identical to mmsim_gemm_bf16); fmt 1 = fp16 A and B, C fp16 or
+ * f32, forward layout only (trans_a 0, b_kmajor 1, no split-K; an fp16 C takes no bias / epilogue) -- the image tower's 1x1
+ * convs and the fc layer of cv_classifier.py:53 on fp16 activations; fmt 2 = weight-gradient layout only (trans_a 1, b_kmajor 0,
+ * f32 C): A is the bf16 gradient, B the fp16 activation, converted to bf16 while it is staged (autograd of the same layers). */
+int mmsim_gemm_fmt(int fmt, int trans_a, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                   void* C, int ldc, int c_is_f32, const float* bias, int epilogue, const void* aux_in, void* aux_out,
+                   int ld_aux, float alpha, int split_k, int accumulate, void* stream);
 
 /* Paired launch of a layer's two backward products.  Between _begin and _end (per host thread, not nestable) the
  * mmsim_gemm_bf16 / mmsim_gemm_bf16_xf calls that would run the generic (ragged-shape) kernel are parked instead of launched
@@ -90,7 +101,7 @@ int mmsim_gemm_group_end(void);
 /* Forward 1x1 conv (xf_operand 0: plain, 1: BN + SiLU (+ gate) applied to A while staged) that also ACCUMULATES the
  * train-mode BatchNorm statistics of its bf16 output into sums [2][N] (sum, sum of squares; pre-zeroed by the caller):
  * replaces conv + the statistics pass of the following nn.BatchNorm2d (timm conv_pw / conv_pwl / conv_head + bn).
- * scratch: >= ceil(M/128) * 2 * N floats. */
+ * scratch: >= ceil(M/128) * 2 * N floats.  A, B and C are fp16 (image-tower forward tensors; the name keeps the family prefix). */
 int mmsim_gemm_bf16_bnstats(int xf_operand, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                             int ldc, const float* xf_scale, const float* xf_shift, const float* xf_gate, int xf_hw,
                             float* sums, float* scratch, unsigned long long scratch_floats, void* stream);
@@ -189,12 +200,19 @@ int mmsim_arcface_rowfix(const void* dcos, const float* cosm, int ld, const floa
 
 /* ---- small glue ------------------------------------------------------------------------------- */
 int mmsim_cast_f32_to_bf16(const float* x, void* y, unsigned long long n, void* stream);
+int mmsim_cast_f32_to_f16(const float* x, void* y, unsigned long long n, void* stream);       /* saturating at +-65504 */
 int mmsim_cast_bf16_to_f32(const void* x, float* y, unsigned long long n, void* stream);
 int mmsim_gather_cls(const void* h, void* out, int B, int S, int H, void* stream);     /* h[:,0] (modeling_bert.py:460) */
 int mmsim_scatter_cls(const void* src, void* dh, int B, int S, int H, void* stream);   /* its backward */
 int mmsim_tanh_bwd(const float* dpooled, const float* pooled, void* dpre, unsigned long long n, void* stream);
 
-/* ---- EfficientNet image tower (timm efficientnet_b0/b4 under cv_classifier.py:23-27,49), NHWC bf16 activations.
+/* ---- EfficientNet image tower (timm efficientnet_b0/b4 under cv_classifier.py:23-27,49), NHWC activations.
+ * ELEMENT TYPES of every entry point of this section: FORWARD tensors -- conv outputs z, activated tensors a / act_out, block
+ * inputs / outputs x, the operand `in` of the depthwise kernels, and the weight shadow the FORWARD 1x1 convs read (w*_f16) -- are
+ * fp16 (IEEE half, round-to-nearest-even, saturating); GRADIENT tensors -- dy, dz, dpre, dx, da, resid of a backward entry point,
+ * `other` of mmsim_pool_bn_act -- and the weight shadow the data-gradient products read (w*_bf16) are bf16.  Why: with bf16
+ * storage of the ~5 stored tensors per MBConv block the image embedding missed north_star's 1e-2 by 3.5-6x (8-bit significand);
+ * fp16 has the same bytes and MFMA rate and an 11-bit significand; gradients need bf16's range.
  * Train-mode BatchNorm2d (eps 1e-5, momentum 0.1): bn_stats accumulates per-channel sum / sum of squares into
  * sums [2][C] (fp32, pre-zeroed); bn_finalize turns them into mean, rstd, scale = gamma*rstd,
  * shift = beta - mean*scale and updates the running statistics; bn_apply writes act(scale*z+shift) (+resid).
@@ -303,7 +321,7 @@ int mmsim_dwtile_bwd(const void* dy, const void* z2, const float* scale2, const 
  * as mmsim_gemm_bf16_bnstats(xf_operand 1, gate only), for the shapes mmsim_pw_project_fwd_eligible accepts (mid <= 384,
  * cout <= 64, HW >= the strip height: the 112^2 / 56^2 / 28^2 stages of B0-B4).  scratch: >= 128 * cout floats. */
 int mmsim_pw_project_fwd_eligible(int P, int HW, int mid, int cout);
-int mmsim_pw_project_fwd(const void* a2, const float* gate, const void* w3_bf16, void* z3, float* sums, int P, int HW, int mid,
+int mmsim_pw_project_fwd(const void* a2, const float* gate, const void* w3_f16, void* z3, float* sums, int P, int HW, int mid,
                          int cout, float* scratch, unsigned long long scratch_floats, void* stream);
 
 /* Expansion 1x1 conv of the 56^2 MBConv stage (timm conv_pw under cv_classifier.py:49) as one streaming pass:
@@ -311,12 +329,12 @@ int mmsim_pw_project_fwd(const void* a2, const float* gate, const void* w3_bf16,
  * sums [2][mid] (pre-zeroed by the caller): the contract of mmsim_gemm_bf16_bnstats(xf_operand 0) for cin <= 32, 64 <= mid <= 192,
  * P % 64 == 0 (mmsim_pw_expand_fwd_eligible).  scratch: >= 128 * mid floats. */
 int mmsim_pw_expand_fwd_eligible(int P, int mid, int cin);
-int mmsim_pw_expand_fwd(const void* x, const void* w1_bf16, void* z1, float* sums, int P, int mid, int cin, float* scratch,
+int mmsim_pw_expand_fwd(const void* x, const void* w1_f16, void* z1, float* sums, int P, int mid, int cin, float* scratch,
                         unsigned long long scratch_floats, void* stream);
 
 /* The two streaming projection kernels with the operand formed on the fly: `z2` is the pre-BatchNorm depthwise output and the operand
  * is silu(xf_scale z2 + xf_shift) * gate -- the activated tensor a2 is then never stored (forward) nor read (backward). */
-int mmsim_pw_project_fwd_xf(const void* z2, const float* xf_scale, const float* xf_shift, const float* gate, const void* w3_bf16,
+int mmsim_pw_project_fwd_xf(const void* z2, const float* xf_scale, const float* xf_shift, const float* gate, const void* w3_f16,
                             void* z3, float* sums, int P, int HW, int mid, int cout, float* scratch,
                             unsigned long long scratch_floats, void* stream);
 int mmsim_pw_project_bwd_xf(const void* dz3, const void* z2, const float* xf_scale, const float* xf_shift, const float* gate,
@@ -352,7 +370,7 @@ int mmsim_bn1d_fwd(const float* x, const float* gamma, const float* beta, float*
                    float* run_mean, float* run_var, int B, int C, float eps, float momentum, int training, void* stream);
 int mmsim_bn1d_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx,
                    float* dgamma, float* dbeta, int B, int C, void* stream);
-int mmsim_dropout_cast(const float* x, void* y_bf16, unsigned long long n, float p, unsigned long long seed,
+int mmsim_dropout_cast(const float* x, void* y_f16, unsigned long long n, float p, unsigned long long seed,
                        unsigned int stream_id, void* stream);
 int mmsim_dropout_bwd(const float* dy, float* dx, unsigned long long n, float p, unsigned long long seed,
                       unsigned int stream_id, void* stream);
@@ -365,6 +383,11 @@ int mmsim_broadcast_pool_grad(const float* dpool, void* dy, int B, int HW, int C
 int mmsim_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, unsigned long long n, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                      const float* dev_hyper, void* stream);
+/* The same with a second, fp16 shadow (may be NULL): the flat buffers of the image tower keep both -- its forward products read
+ * the weights as fp16, its data-gradient products as bf16 (EfficientNet section). */
+int mmsim_adamw_step2(float* p, const float* g, float* m, float* v, void* bf16_shadow, void* f16_shadow, unsigned long long n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                      const float* dev_hyper, void* stream);
 
 /* The same update for a row-normalised weight matrix p [R][D] (the ArcFace head), one wave per row, which also leaves
  * w_hat bf16 [R][D] = p / max(||p_row||, l2_eps) and inv_norm [R] for the NEXT forward: F.normalize(self.weight) (arcface.py:47)

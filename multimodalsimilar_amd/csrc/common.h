@@ -10,6 +10,14 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
 typedef __attribute__((ext_vector_type(4))) float f4;
 typedef __attribute__((ext_vector_type(16))) float f16v;
+// fp16: the storage type of the IMAGE tower's forward tensors (conv outputs, activations, its 1x1-conv weight shadow).  Same
+// bytes and MFMA rate as bf16 with an 11-bit significand instead of 8: bf16 storage alone moved the image embedding by 3.5-5 %
+// (north_star: 1e-2), fp16 by 0.6 % (oracle/effnet_ref.py emulate="fp16").  Gradients stay bf16 (range: per-element
+// gradients of a 112x112 map sit below fp16's normal range).
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+typedef __attribute__((ext_vector_type(2))) _Float16 h2;
 typedef __attribute__((ext_vector_type(4))) short s4;
 typedef __attribute__((ext_vector_type(8))) short s8;
 
@@ -50,6 +58,9 @@ __device__ __forceinline__ void fdivmod(unsigned int n, const FastDiv& f, int& q
 
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
+__device__ __forceinline__ float h2f(f16 x) { return (float)x; }
+// round-to-nearest-even, saturating at +-65504 (a conv output beyond fp16's range must not become inf -> NaN downstream)
+__device__ __forceinline__ f16 f2h(float x) { return (f16)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1,4 +1,6 @@
-// EfficientNet (MBConv) kernels for gfx950, NHWC bf16 activations, fp32 statistics.
+// EfficientNet (MBConv) kernels for gfx950, NHWC activations, fp32 statistics.
+// Element types: every FORWARD tensor (conv outputs z, activations a, block outputs x) is fp16 (f16: 11-bit significand -- bf16
+// storage alone cost 3.5-5 % on the image embedding, see common.h); every GRADIENT tensor (dy, dz, dx, resid) is bf16 (range).
 // The image tower is HBM-bound: every kernel here maps a thread to one 8-channel octet
 // (one 16-byte access) so a wave reads whole contiguous pixel rows, keeps its channel octet fixed so
 // per-channel reductions (BatchNorm batch statistics, BN/SE backward sums, depthwise weight gradients)
@@ -78,10 +80,22 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   for (int e = 0; e < 8; ++e) b[e] = f2bf(f[e]);
   return __builtin_bit_cast(uint4, b);
 }
+// the same for fp16 chunks (forward tensors)
+__device__ __forceinline__ void unpack8h(const uint4& v, float (&f)[8]) {
+  const h8 b = __builtin_bit_cast(h8, v);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = h2f(b[e]);
+}
+__device__ __forceinline__ uint4 pack8h(const float (&f)[8]) {
+  h8 b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) b[e] = f2h(f[e]);
+  return __builtin_bit_cast(uint4, b);
+}
 // Bounds-masked 16-byte load: the ADDRESS is always valid (callers clamp the coordinates) and the value is zeroed
 // afterwards.  Writing `ok ? *p : 0` instead makes hipcc branch around every load and wait vmcnt(0) per element --
 // the loads of a row then complete one L2 round trip after the other (cdna_hip_programming.md section 5, trap 4c).
-__device__ __forceinline__ uint4 ld16_masked(const bf16* p, bool ok) {
+__device__ __forceinline__ uint4 ld16_masked(const void* p, bool ok) {
   const uint4 v = *reinterpret_cast<const uint4*>(p);
   const unsigned int msk = ok ? 0xffffffffu : 0u;          // AND, not select: hipcc turns select-of-load back into a branch
   return make_uint4(v.x & msk, v.y & msk, v.z & msk, v.w & msk);
@@ -223,7 +237,7 @@ void mmsim_launch_reduce(const float* parts, int nparts, int n, float* out, int 
 }
 
 // ------------------------------------------------------------------ BN statistics
-__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* __restrict__ z, float* parts, int P, int C, int rows_per_block) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const f16* __restrict__ z, float* parts, int P, int C, int rows_per_block) {
   __shared__ float lds[256 * 16];
   const CgMap m = cg_map(C);
   float acc[16];
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* __restrict__ 
 #pragma unroll 4
     for (int r = r0 + m.rl; r < r1; r += m.nr) {
       float f[8];
-      unpack8(*reinterpret_cast<const uint4*>(z + (size_t)r * C + m.cg * 8), f);
+      unpack8h(*reinterpret_cast<const uint4*>(z + (size_t)r * C + m.cg * 8), f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { acc[e] += f[e]; acc[8 + e] += f[e] * f[e]; }
     }
@@ -261,30 +275,30 @@ __global__ void bn_finalize_kernel(const float* sums, const float* gamma, const 
 }
 
 // out = act(scale*z + shift) (+ resid)
-__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* z, const float* scale, const float* shift,
-                                                       const bf16* resid, bf16* out, size_t nchunks, int C, int act) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(const f16* z, const float* scale, const float* shift,
+                                                       const f16* resid, f16* out, size_t nchunks, int C, int act) {
   for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nchunks; q += (size_t)gridDim.x * 256) {
     const int c0 = (int)((q * 8) % (size_t)C);
     float f[8], sc[8], sh[8];
-    unpack8(*reinterpret_cast<const uint4*>(z + q * 8), f);
+    unpack8h(*reinterpret_cast<const uint4*>(z + q * 8), f);
     ld8f(scale + c0, sc); ld8f(shift + c0, sh);
 #pragma unroll
     for (int e = 0; e < 8; ++e) { f[e] = f[e] * sc[e] + sh[e]; if (act) f[e] = silu_f(f[e]); }
     if (resid) {
       float r[8];
-      unpack8(*reinterpret_cast<const uint4*>(resid + q * 8), r);
+      unpack8h(*reinterpret_cast<const uint4*>(resid + q * 8), r);
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] += r[e];
     }
-    *reinterpret_cast<uint4*>(out + q * 8) = pack8(f);
+    *reinterpret_cast<uint4*>(out + q * 8) = pack8h(f);
   }
 }
 
 // out[b,c] = mul * sum_hw act(scale*z+shift)[b,hw,c] * (other ? other[b,hw,c] : 1)      (fp32 [B,C])
-__global__ __launch_bounds__(256) void pool_bn_act_kernel(const bf16* __restrict__ z, const float* __restrict__ scale,
+__global__ __launch_bounds__(256) void pool_bn_act_kernel(const f16* __restrict__ z, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const bf16* __restrict__ other,
                                                           float* out, int HW, int C, int act, float mul, int rows_per_z,
-                                                          bf16* __restrict__ act_out) {
+                                                          f16* __restrict__ act_out) {
   __shared__ float lds[256 * 8];
   const CgMap m = pool_map(C);
   const int lc = threadIdx.x % m.G;
@@ -297,8 +311,8 @@ __global__ __launch_bounds__(256) void pool_bn_act_kernel(const bf16* __restrict
     ld8f(scale + m.cg * 8, sc); ld8f(shift + m.cg * 8, sh);
     const int rbeg = blockIdx.z * rows_per_z, rend = min(HW, rbeg + rows_per_z);
     // four rows per trip, all (bounds-masked) loads requested before the first use
-    const bf16* zb = z + (size_t)b * HW * C + m.cg * 8;
-    const bf16* ob = other ? other + (size_t)b * HW * C + m.cg * 8 : nullptr;
+    const f16* zb = z + (size_t)b * HW * C + m.cg * 8;
+    const bf16* ob = other ? other + (size_t)b * HW * C + m.cg * 8 : nullptr;      // a gradient tensor (bf16)
     for (int r = rbeg + m.rl; r < rend; r += 4 * m.nr) {
       uint4 zr[4], orr[4];
       bool ok[4];
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(256) void pool_bn_act_kernel(const bf16* __restrict
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float f[8];
-        unpack8(zr[q], f);
+        unpack8h(zr[q], f);
         if (ob) {
           float o[8];
           unpack8(orr[q], o);            // zero for rows past the end: they add nothing
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(256) void pool_bn_act_kernel(const bf16* __restrict
           for (int e = 0; e < 8; ++e) { float y = f[e] * sc[e] + sh[e]; if (act) y = silu_f(y); y8[e] = y; acc[e] += ok[q] ? y : 0.f; }
           // the activated tensor kept for the projection conv (its operand is then a2 * gate: one multiply per element in
           // the GEMM's staging instead of BN + SiLU + gate, which made those products VALU-bound)
-          if (act_out && ok[q]) *reinterpret_cast<uint4*>(act_out + ((size_t)b * HW + r + q * m.nr) * C + m.cg * 8) = pack8(y8);
+          if (act_out && ok[q]) *reinterpret_cast<uint4*>(act_out + ((size_t)b * HW + r + q * m.nr) * C + m.cg * 8) = pack8h(y8);
         }
       }
     }
@@ -486,7 +500,7 @@ __global__ __launch_bounds__(64) void se_wgrad_kernel(const float* __restrict__ 
 // The BN-backward sums of da = (dy gate + dsq / HW) a' are then  S1[c] = sum_b gate P1 + dsq/HW P2,  S2[c] = sum_b gate P3 +
 // dsq/HW P4 (bn_bwd_sums_from_pool_kernel) -- dsq only exists after the SE backward, which needs dgate, so without this
 // regrouping the reduction costs a second full pass over both tensors (bn_bwd_reduce_kernel).
-__global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const bf16* __restrict__ z, const float* __restrict__ scale,
+__global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const f16* __restrict__ z, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const bf16* __restrict__ dy,
                                                           float* out5, int B, int HW, int C, int rows_per_z) {
@@ -503,7 +517,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const bf16* __restrict
     float sc[8], sh[8], mu[8], rs[8];
     ld8f(scale + m.cg * 8, sc); ld8f(shift + m.cg * 8, sh); ld8f(mean + m.cg * 8, mu); ld8f(rstd + m.cg * 8, rs);
     const int rbeg = blockIdx.z * rows_per_z, rend = min(HW, rbeg + rows_per_z);
-    const bf16* zb = z + (size_t)b * HW * C + m.cg * 8;
+    const f16* zb = z + (size_t)b * HW * C + m.cg * 8;
     const bf16* db = dy + (size_t)b * HW * C + m.cg * 8;
     for (int r = rbeg + m.rl; r < rend; r += 4 * m.nr) {
       uint4 zr[4], dr[4];
@@ -518,7 +532,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const bf16* __restrict
       for (int q = 0; q < 4; ++q) {
         const float ok = (r + q * m.nr < rend) ? 1.f : 0.f;     // a' of a masked (zero) z is not zero
         float f[8], d[8];
-        unpack8(zr[q], f); unpack8(dr[q], d);
+        unpack8h(zr[q], f); unpack8(dr[q], d);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float u = f[e] * sc[e] + sh[e], sg = sigmoid_f(u);
@@ -579,7 +593,7 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_from_pool_kernel(const float*
 }
 
 struct BnBwd {
-  const bf16* dy; const bf16* z; const float* mean; const float* rstd; const float* scale; const float* shift;
+  const bf16* dy; const f16* z; const float* mean; const float* rstd; const float* scale; const float* shift;
   const float* gate; const float* dsq; int hw; int act; int P; int C; float inv_hw; FastDiv d_hw;
 };
 // da = (gate ? dy*g + dsq/HW : dy) * (act ? silu'(scale*z+shift) : 1)
@@ -595,7 +609,7 @@ __device__ __forceinline__ void bn_bwd_elem(const BnBwd& p, const BnBwdCh& ch, i
                                             float (&da)[8], float (&zh)[8]) {
   float d[8], z[8];
   unpack8(dv, d);
-  unpack8(zv, z);
+  unpack8h(zv, z);
   if (p.gate) {
     const int b = (int)fdiv((unsigned int)r, p.d_hw);
     float g[8], q[8];
@@ -717,7 +731,7 @@ struct DwGeom { int B, Hi, Wi, Ho, Wo, C; FastDiv d_strip, d_rows; };   // d_str
 // V = 0: one kernel row at a time (few registers);  V = 1: all K x NIN input chunks of an item are requested up front and
 // kept PACKED (bf16) until used, so a thread has K x NIN 16-byte loads in flight instead of NIN (latency-bound otherwise)
 template <int K, int S, int TW, int V>
-__global__ __launch_bounds__(256) DW_OCC void dwconv_fwd_kernel(const bf16* __restrict__ a, const float* __restrict__ wT, bf16* z, float* parts, DwGeom g,
+__global__ __launch_bounds__(256) DW_OCC void dwconv_fwd_kernel(const f16* __restrict__ a, const float* __restrict__ wT, f16* z, float* parts, DwGeom g,
                                                          int items_per_block) {
   constexpr int PAD = K / 2, NIN = (TW - 1) * S + K;
   __shared__ float lds[256 * 16];
@@ -760,7 +774,7 @@ __global__ __launch_bounds__(256) DW_OCC void dwconv_fwd_kernel(const bf16* __re
 #pragma unroll
             for (int j = 0; j < TW; ++j) {
               float in[8];
-              unpack8(pk[kh][j * S + kw], in);
+              unpack8h(pk[kh][j * S + kw], in);
 #pragma unroll
               for (int e = 0; e < 8; ++e) acc[j][e] += in[e] * w[e];
             }
@@ -772,7 +786,7 @@ __global__ __launch_bounds__(256) DW_OCC void dwconv_fwd_kernel(const bf16* __re
         auto load_row = [&](int kh, uint4 (&dst)[NIN]) {
           const int hi = ho * S - PAD + kh;
           const bool hv = hi >= 0 && hi < g.Hi;
-          const bf16* arow = a + ((size_t)b * g.Hi + clampi(hi, 0, g.Hi - 1)) * g.Wi * g.C + m.cg * 8;
+          const f16* arow = a + ((size_t)b * g.Hi + clampi(hi, 0, g.Hi - 1)) * g.Wi * g.C + m.cg * 8;
 #pragma unroll
           for (int x = 0; x < NIN; ++x) {
             const int wi = wo0 * S - PAD + x;
@@ -786,7 +800,7 @@ __global__ __launch_bounds__(256) DW_OCC void dwconv_fwd_kernel(const bf16* __re
           if (kh + 1 < K) load_row(kh + 1, nxt);
           float in[NIN][8];
 #pragma unroll
-          for (int x = 0; x < NIN; ++x) unpack8(raw[x], in[x]);
+          for (int x = 0; x < NIN; ++x) unpack8h(raw[x], in[x]);
 #pragma unroll
           for (int kw = 0; kw < K; ++kw) {
             float w[8];
@@ -803,10 +817,10 @@ __global__ __launch_bounds__(256) DW_OCC void dwconv_fwd_kernel(const bf16* __re
 #pragma unroll
       for (int j = 0; j < TW; ++j) {
         if (wo0 + j < g.Wo) {
-          const uint4 o = pack8(acc[j]);
+          const uint4 o = pack8h(acc[j]);
           *reinterpret_cast<uint4*>(z + (((size_t)b * g.Ho + ho) * g.Wo + wo0 + j) * g.C + m.cg * 8) = o;
           float r[8];
-          unpack8(o, r);
+          unpack8h(o, r);
 #pragma unroll
           for (int e = 0; e < 8; ++e) { st[e] += r[e]; st[8 + e] += r[e] * r[e]; }
         }
@@ -820,7 +834,7 @@ __global__ __launch_bounds__(256) DW_OCC void dwconv_fwd_kernel(const bf16* __re
 // fused: dpre = da * silu'(scale*z1+shift) written to `out`, and BN-backward sums (sum dpre, sum dpre*zhat) of the
 // producer's BatchNorm accumulated per channel.  thread = (octet, strip of TW input pixels along W)
 template <int K, int S>
-__global__ __launch_bounds__(256) DW_OCC void dwconv_bwd_data_kernel(const bf16* dz, const float* wT, const bf16* z1, const float* mean,
+__global__ __launch_bounds__(256) DW_OCC void dwconv_bwd_data_kernel(const bf16* dz, const float* wT, const f16* z1, const float* mean,
                                                               const float* rstd, const float* scale, const float* shift,
                                                               const bf16* resid, bf16* out, float* parts, DwGeom g,
                                                               int items_per_block) {
@@ -940,12 +954,12 @@ __global__ __launch_bounds__(256) DW_OCC void dwconv_bwd_data_kernel(const bf16*
       }
       }
       // epilogue operands (z1 or the residual gradient) of all four pixels requested together, bounds-masked
-      const bf16* eptr = z1 ? z1 : resid;
+      const char* eptr = z1 ? reinterpret_cast<const char*>(z1) : reinterpret_cast<const char*>(resid);      // 2-byte elements both: z1 fp16, resid bf16
       uint4 er[TW];
       const size_t off0 = (((size_t)b * g.Hi + hi) * g.Wi) * g.C + c0;
       if (eptr) {
 #pragma unroll
-        for (int j = 0; j < TW; ++j) er[j] = ld16_masked(eptr + off0 + (size_t)min(wi0 + j, g.Wi - 1) * g.C, wi0 + j < g.Wi);
+        for (int j = 0; j < TW; ++j) er[j] = ld16_masked(eptr + 2 * (off0 + (size_t)min(wi0 + j, g.Wi - 1) * g.C), wi0 + j < g.Wi);
       }
 #pragma unroll
       for (int j = 0; j < TW; ++j) {
@@ -954,7 +968,7 @@ __global__ __launch_bounds__(256) DW_OCC void dwconv_bwd_data_kernel(const bf16*
           float o[8];
           if (z1) {
             float zz[8];
-            unpack8(er[j], zz);
+            unpack8h(er[j], zz);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = acc[j][e] * silu_grad_f(zz[e] * sc[e] + sh[e]);
             const uint4 pk = pack8(o);
@@ -982,7 +996,7 @@ __global__ __launch_bounds__(256) DW_OCC void dwconv_bwd_data_kernel(const bf16*
 
 // backward weight (tap-major gT [K*K][C]): one kernel row kh per blockIdx.z; thread = (octet, output row lane)
 template <int K, int S>
-__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16* __restrict__ dz, const bf16* __restrict__ a, float* parts, DwGeom g,
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16* __restrict__ dz, const f16* __restrict__ a, float* parts, DwGeom g,
                                                                 int rows_per_block, const float* __restrict__ xf_scale,
                                                                 const float* __restrict__ xf_shift) {
   constexpr int PAD = K / 2;
@@ -1004,7 +1018,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16* __re
       const int ho = r % g.Ho, b = r / g.Ho;
       const int hi = ho * S - PAD + kh;
       if (hi < 0 || hi >= g.Hi) continue;
-      const bf16* arow = a + (((size_t)b * g.Hi + hi) * g.Wi) * g.C + c0;
+      const f16* arow = a + (((size_t)b * g.Hi + hi) * g.Wi) * g.C + c0;
       const bf16* drow = dz + (((size_t)b * g.Ho + ho) * g.Wo) * g.C + c0;
       // strips of 4 output pixels: 4 dz chunks + (3 S + K) input chunks requested together (bounds-masked, no branches)
       constexpr int NIN = 3 * S + K;
@@ -1019,14 +1033,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const bf16* __re
         }
         float xin[NIN][8];
 #pragma unroll
-        for (int x = 0; x < NIN; ++x) unpack8(ar[x], xin[x]);
+        for (int x = 0; x < NIN; ++x) unpack8h(ar[x], xin[x]);
         if (xf_scale) {
 #pragma unroll
           for (int x = 0; x < NIN; ++x) {
             const int wi = w0 * S - PAD + x;
             const float ok = (wi >= 0 && wi < g.Wi) ? 1.f : 0.f;          // the zero padding is of the ACTIVATED tensor
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xin[x][e] = bf2f(f2bf(silu_f(xin[x][e] * sc[e] + sh[e]))) * ok;      // rounded as the stored a1 was
+            for (int e = 0; e < 8; ++e) xin[x][e] = h2f(f2h(silu_f(xin[x][e] * sc[e] + sh[e]))) * ok;      // rounded as the forward's staged a1 was
           }
         }
 #pragma unroll
@@ -1055,7 +1069,7 @@ struct StemGeom { int B, Hi, Wi, Ho, Wo, Co; FastDiv d_wo, d_ho; };
 __device__ __forceinline__ void stem_tap(int tap, int& ci, int& kh, int& kw) { ci = tap / 9; kh = (tap - ci * 9) / 3; kw = tap - ci * 9 - kh * 3; }
 
 template <int CT>
-__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, bf16* z, float* parts,
+__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, f16* z, float* parts,
                                                             StemGeom g, int pix_per_block) {
   __shared__ float red[4][128];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, kg = lane >> 4;
@@ -1102,12 +1116,12 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ct], xf, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct], xl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct], xf, acc, 0, 0, 0);
-      const bf4 o = {f2bf(acc[0]), f2bf(acc[1]), f2bf(acc[2]), f2bf(acc[3])};
+      const h4 o = {f2h(acc[0]), f2h(acc[1]), f2h(acc[2]), f2h(acc[3])};
       const int c0 = 16 * ct + 4 * kg;
       if (pv && c0 < g.Co) {
-        *reinterpret_cast<bf4*>(z + (size_t)p * g.Co + c0) = o;
+        *reinterpret_cast<h4*>(z + (size_t)p * g.Co + c0) = o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float r = bf2f(o[e]); st[ct][e] += r; sq[ct][e] += r * r; }
+        for (int e = 0; e < 4; ++e) { const float r = h2f(o[e]); st[ct][e] += r; sq[ct][e] += r * r; }
       }
     }
   }
@@ -1258,13 +1272,13 @@ __global__ void bn1d_bwd_kernel(const float* dy, const float* x, const float* me
 }
 
 // elementwise helpers for the tower top
-__global__ void dropout_cast_kernel(const float* x, bf16* y, size_t n, unsigned long long seed, unsigned int stream, unsigned int thresh,
+__global__ void dropout_cast_kernel(const float* x, f16* y, size_t n, unsigned long long seed, unsigned int stream, unsigned int thresh,
                                     float inv_keep, const unsigned long long* seed_dev) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float v = x[i];
   if (thresh) v = drop_keep(step_seed(seed, seed_dev), stream, i, thresh) ? v * inv_keep : 0.f;
-  y[i] = f2bf(v);
+  y[i] = f2h(v);
 }
 __global__ void dropout_bwd_kernel(const float* dy, float* dx, size_t n, unsigned long long seed, unsigned int stream, unsigned int thresh,
                                    float inv_keep, const unsigned long long* seed_dev) {
@@ -1308,7 +1322,7 @@ extern "C" int mmsim_bn_stats(const void* z, float* sums, int P, int C, float* s
   const int rpb = rows_per_block_for(P, nr_of(C));
   const int nparts = (P + rpb - 1) / rpb;
   REQ_SCRATCH((size_t)nparts * 2 * C, "bn_stats");
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(nparts, cg_grid_y(C)), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scratch, P, C, rpb);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nparts, cg_grid_y(C)), dim3(256), 0, (hipStream_t)stream, (const f16*)z, scratch, P, C, rpb);
   launch_reduce(scratch, nparts, 2 * C, sums, 1, (hipStream_t)stream);      /* sums are pre-zeroed by the caller (header contract) */
   return mmsim_check_launch("bn_stats");
 }
@@ -1350,8 +1364,8 @@ extern "C" int mmsim_bn_apply(const void* z, const float* scale, const float* sh
   MMSIM_REQUIRE(z && scale && shift && out && P > 0, "bn_apply: bad arguments"); REQ_C8(C, "bn_apply");
   const size_t nch = (size_t)P * C / 8;
   size_t gsz = (nch + 255) / 256; if (gsz > 16384) gsz = 16384;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scale, shift,
-                     (const bf16*)resid, (bf16*)out, nch, C, act_silu);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, (const f16*)z, scale, shift,
+                     (const f16*)resid, (f16*)out, nch, C, act_silu);
   return mmsim_check_launch("bn_apply");
 }
 
@@ -1364,8 +1378,8 @@ static int pool_bn_act_impl(const void* z, const float* scale, const float* shif
   while (!mmsim_deterministic() && nz < 16 && HW / (nz * 2 * nr) >= 16 && B * gy * nz < 2048) nz *= 2;      // >= 16 rows per row lane and z-slice: a slice costs 8 C atomics
   const int rpz = (HW + nz - 1) / nz;
   if (nz > 1) (void)hipMemsetAsync(out, 0, (size_t)B * C * sizeof(float), (hipStream_t)stream);
-  hipLaunchKernelGGL(pool_bn_act_kernel, dim3(B, gy, nz), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scale, shift,
-                     (const bf16*)other, out, HW, C, act_silu, mul, rpz, (bf16*)act_out);
+  hipLaunchKernelGGL(pool_bn_act_kernel, dim3(B, gy, nz), dim3(256), 0, (hipStream_t)stream, (const f16*)z, scale, shift,
+                     (const bf16*)other, out, HW, C, act_silu, mul, rpz, (f16*)act_out);
   return mmsim_check_launch("pool_bn_act");
 }
 
@@ -1389,7 +1403,7 @@ extern "C" int mmsim_pool_bn_bwd(const void* z, const float* scale, const float*
   while (!mmsim_deterministic() && nz < 16 && HW / (nz * 2 * nr) >= 16 && B * gy * nz < 2048) nz *= 2;
   const int rpz = (HW + nz - 1) / nz;
   if (nz > 1) (void)hipMemsetAsync(out5, 0, (size_t)5 * B * C * sizeof(float), (hipStream_t)stream);
-  hipLaunchKernelGGL(pool_bn_bwd_kernel, dim3(B, gy, nz), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, scale, shift,
+  hipLaunchKernelGGL(pool_bn_bwd_kernel, dim3(B, gy, nz), dim3(256), 0, (hipStream_t)stream, (const f16*)z, scale, shift,
                      mean, rstd, (const bf16*)dy, out5, B, HW, C, rpz);
   return mmsim_check_launch("pool_bn_bwd");
 }
@@ -1443,7 +1457,7 @@ extern "C" int mmsim_se_mlp_bwd(const float* dgate, const float* gate, const flo
 static BnBwd mk_bnbwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* scale, const float* shift,
                       const float* gate, const float* dsq, int hw, int act, int P, int C) {
   BnBwd p;
-  p.dy = (const bf16*)dy; p.z = (const bf16*)z; p.mean = mean; p.rstd = rstd; p.scale = scale; p.shift = shift;
+  p.dy = (const bf16*)dy; p.z = (const f16*)z; p.mean = mean; p.rstd = rstd; p.scale = scale; p.shift = shift;
   p.gate = gate; p.dsq = dsq; p.hw = hw > 0 ? hw : 1; p.act = act; p.P = P; p.C = C; p.inv_hw = 1.0f / (float)(hw > 0 ? hw : 1); p.d_hw = make_fastdiv(hw > 0 ? hw : 1);
   return p;
 }
@@ -1504,7 +1518,7 @@ extern "C" int mmsim_dwconv_fwd(const void* a, const float* w_tap_major, void* z
   const int ipb = rows_per_block_for(nitems, nr_of(C));
   dim3 grid((nitems + ipb - 1) / ipb, cg_grid_y(C));
   REQ_SCRATCH((size_t)grid.x * 2 * C, "dwconv_fwd");
-#define DWF(KK, SS, TT, VV) hipLaunchKernelGGL((dwconv_fwd_kernel<KK, SS, TT, VV>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)a, w_tap_major, (bf16*)z, scratch, g, ipb)
+#define DWF(KK, SS, TT, VV) hipLaunchKernelGGL((dwconv_fwd_kernel<KK, SS, TT, VV>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)a, w_tap_major, (f16*)z, scratch, g, ipb)
 #define DWF_KS(TT, VV)                                        \
   if (K == 3 && S == 1) DWF(3, 1, TT, VV); else if (K == 3 && S == 2) DWF(3, 2, TT, VV); \
   else if (K == 5 && S == 1) DWF(5, 1, TT, VV); else DWF(5, 2, TT, VV);
@@ -1528,7 +1542,7 @@ extern "C" int mmsim_dwconv_bwd_data(const void* dz, const float* w_tap_major, c
   const int ipb = rows_per_block_for(nitems, nr_of(C));
   dim3 grid((nitems + ipb - 1) / ipb, cg_grid_y(C));
   if (z1) REQ_SCRATCH((size_t)grid.x * 2 * C, "dwconv_bwd_data");
-  DW_DISPATCH(dwconv_bwd_data_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, w_tap_major, (const bf16*)z1, mean,
+  DW_DISPATCH(dwconv_bwd_data_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, w_tap_major, (const f16*)z1, mean,
               rstd, scale, shift, (const bf16*)resid, (bf16*)dpre, scratch, g, ipb)
   if (z1) launch_reduce(scratch, grid.x, 2 * C, sums, 1, (hipStream_t)stream);
   return mmsim_check_launch("dwconv_bwd_data");
@@ -1554,7 +1568,7 @@ static int dwconv_bwd_weight_impl(const void* dz, const void* a, const float* xf
   int rpb = (nrows + 127) / 128; const int nr = nr_of(C); if (rpb < nr) rpb = nr;
   dim3 grid((nrows + rpb - 1) / rpb, cg_grid_y(C), K);
   REQ_SCRATCH((size_t)grid.x * K * K * C, "dwconv_bwd_weight");
-  DW_DISPATCH(dwconv_bwd_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, (const bf16*)a, scratch, g, rpb, xf_scale, xf_shift)
+  DW_DISPATCH(dwconv_bwd_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, (const f16*)a, scratch, g, rpb, xf_scale, xf_shift)
   launch_reduce(scratch, grid.x, K * K * C, g_tap_major, 1, (hipStream_t)stream);      /* g_tap_major += */
   return mmsim_check_launch("dwconv_bwd_weight");
 }
@@ -1578,10 +1592,10 @@ extern "C" int mmsim_stem_fwd(const float* x, const float* w, void* z, float* su
   const int nparts = (npix + ppb - 1) / ppb;
   REQ_SCRATCH((size_t)nparts * 2 * Co, "stem_fwd");
   const int CT = (Co + 15) / 16;
-  if (CT == 1) hipLaunchKernelGGL((stem_fwd_mfma_kernel<1>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)z, scratch, g, ppb);
-  else if (CT == 2) hipLaunchKernelGGL((stem_fwd_mfma_kernel<2>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)z, scratch, g, ppb);
-  else if (CT == 3) hipLaunchKernelGGL((stem_fwd_mfma_kernel<3>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)z, scratch, g, ppb);
-  else hipLaunchKernelGGL((stem_fwd_mfma_kernel<4>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)z, scratch, g, ppb);
+  if (CT == 1) hipLaunchKernelGGL((stem_fwd_mfma_kernel<1>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, w, (f16*)z, scratch, g, ppb);
+  else if (CT == 2) hipLaunchKernelGGL((stem_fwd_mfma_kernel<2>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, w, (f16*)z, scratch, g, ppb);
+  else if (CT == 3) hipLaunchKernelGGL((stem_fwd_mfma_kernel<3>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, w, (f16*)z, scratch, g, ppb);
+  else hipLaunchKernelGGL((stem_fwd_mfma_kernel<4>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, w, (f16*)z, scratch, g, ppb);
   launch_reduce(scratch, nparts, 2 * Co, sums, 1, (hipStream_t)stream);
   return mmsim_check_launch("stem_fwd");
 }
@@ -1619,11 +1633,11 @@ extern "C" int mmsim_bn1d_bwd(const float* dy, const float* x, const float* mean
   return mmsim_check_launch("bn1d_bwd");
 }
 
-extern "C" int mmsim_dropout_cast(const float* x, void* y_bf16, unsigned long long n, float p, unsigned long long seed,
+extern "C" int mmsim_dropout_cast(const float* x, void* y_f16, unsigned long long n, float p, unsigned long long seed,
                                   unsigned int stream_id, void* stream) {
-  MMSIM_REQUIRE(x && y_bf16 && p >= 0.f && p < 1.f, "dropout_cast: bad arguments");
+  MMSIM_REQUIRE(x && y_f16 && p >= 0.f && p < 1.f, "dropout_cast: bad arguments");
   if (n == 0) return MMSIM_OK;
-  hipLaunchKernelGGL(dropout_cast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)y_bf16,
+  hipLaunchKernelGGL(dropout_cast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (f16*)y_f16,
                      (size_t)n, seed, stream_id, p > 0.f ? (unsigned int)((double)p * 4294967296.0) : 0u, 1.0f / (1.0f - p), mmsim_step_seed_ptr());
   return mmsim_check_launch("dropout_cast");
 }

@@ -90,7 +90,33 @@ __device__ __forceinline__ void xform_request(const GemmParams& p, int r0, int R
   }
 }
 
-template <bool TRANS>
+// FMT (GemmParams::fmt): 0 bf16 in / bf16 out, 1 fp16 in / fp16 out, 2 fp16 in / bf16 out (the weight gradient's activation operand)
+template <int FMT> __device__ __forceinline__ float xf_in(const uint4& v, int e) {
+  if (FMT == 0) return bf2f(__builtin_bit_cast(bf8, v)[e]);
+  return h2f(__builtin_bit_cast(h8, v)[e]);
+}
+template <int FMT> __device__ __forceinline__ uint4 xf_out(const float (&f)[8]) {
+  if (FMT == 1) { h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2h(f[e]);
+    return __builtin_bit_cast(uint4, o); }
+  bf8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(f[e]);
+  return __builtin_bit_cast(uint4, o);
+}
+// fmt 2 without an operand transform: the fp16 activation tile becomes bf16 in registers on its way to LDS (zeros stay zeros)
+__device__ __forceinline__ void convert_tile_f16_bf16(uint4 (&reg)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = xf_in<2>(reg[i], e);
+    reg[i] = xf_out<2>(f);
+  }
+}
+
+template <bool TRANS, int FMT>
 __device__ __forceinline__ void xform_tile(const GemmParams& p, int r0, int R, int k0, int kend, int tid, uint4 (&reg)[4], const XfGate& xg) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -99,23 +125,23 @@ __device__ __forceinline__ void xform_tile(const GemmParams& p, int r0, int R, i
     bool ok;
     if (!TRANS) { pix = r0 + (c >> 3); ch = k0 + (c & 7) * 8; ok = pix < R && ch < kend; if (pix >= R) pix = R - 1; if (ch >= kend) ch = k0; }
     else { pix = k0 + (c >> 4); ch = r0 + (c & 15) * 8; ok = pix < kend && ch < R; if (pix >= kend) pix = kend - 1; if (ch >= R) ch = r0; }
-    const bf8 v = __builtin_bit_cast(bf8, reg[i]);
+    const uint4 v = reg[i];
     const float g[8] = {xg.g0[i].x, xg.g0[i].y, xg.g0[i].z, xg.g0[i].w, xg.g1[i].x, xg.g1[i].y, xg.g1[i].z, xg.g1[i].w};
     if (!p.xf_scale) {                   // launch-uniform: the operand is already activated, only the SE gate remains
-      bf8 o;
+      float o[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(v[e]) * g[e]);      // masked (zero) elements stay zero
-      reg[i] = __builtin_bit_cast(uint4, o);
+      for (int e = 0; e < 8; ++e) o[e] = xf_in<FMT>(v, e) * g[e];      // masked (zero) elements stay zero
+      reg[i] = xf_out<FMT>(o);
       continue;
     }
     const float4 s0 = *reinterpret_cast<const float4*>(p.xf_scale + ch), s1 = *reinterpret_cast<const float4*>(p.xf_scale + ch + 4);
     const float4 h0 = *reinterpret_cast<const float4*>(p.xf_shift + ch), h1 = *reinterpret_cast<const float4*>(p.xf_shift + ch + 4);
     const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
     const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-    bf8 o;
+    float o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = f2bf(silu_f(bf2f(v[e]) * sc[e] + sh[e]) * (p.xf_gate ? g[e] : 1.f));
-    const uint4 ov = __builtin_bit_cast(uint4, o);
+    for (int e = 0; e < 8; ++e) o[e] = silu_f(xf_in<FMT>(v, e) * sc[e] + sh[e]) * (p.xf_gate ? g[e] : 1.f);
+    const uint4 ov = xf_out<FMT>(o);
     const unsigned int msk = ok ? 0xffffffffu : 0u;      // out-of-range elements must stay zero (silu(shift) != 0)
     reg[i] = make_uint4(ov.x & msk, ov.y & msk, ov.z & msk, ov.w & msk);
   }
@@ -142,8 +168,9 @@ __device__ __forceinline__ bf8 read_frag(const char* lds, int rbase, int ks, int
   }
 }
 
-template <bool TA, bool TB_KMAJOR, int XF>   // XF: 0 none, 1 transform A, 2 transform B
+template <bool TA, bool TB_KMAJOR, int XF, int FMT = 0>   // XF: 0 none, 1 transform A, 2 transform B; FMT: GemmParams::fmt
 __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, char* smem) {
+  static_assert(FMT != 2 || (XF != 1), "fmt 2 converts the B operand");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
@@ -170,8 +197,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, ch
   XfGate xg;
   load_tile<TA>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
   load_tile<!TB_KMAJOR>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb);
-  if (XF == 1) { xform_request<TA>(p, m0, p.M, kbeg, kend, tid, xg); xform_tile<TA>(p, m0, p.M, kbeg, kend, tid, ra, xg); }
-  if (XF == 2) { xform_request<!TB_KMAJOR>(p, n0, p.N, kbeg, kend, tid, xg); xform_tile<!TB_KMAJOR>(p, n0, p.N, kbeg, kend, tid, rb, xg); }
+  if (XF == 1) { xform_request<TA>(p, m0, p.M, kbeg, kend, tid, xg); xform_tile<TA, FMT>(p, m0, p.M, kbeg, kend, tid, ra, xg); }
+  if (XF == 2) { xform_request<!TB_KMAJOR>(p, n0, p.N, kbeg, kend, tid, xg); xform_tile<!TB_KMAJOR, FMT>(p, n0, p.N, kbeg, kend, tid, rb, xg); }
+  if (FMT == 2 && XF == 0) convert_tile_f16_bf16(rb);
   store_tile<TA>(smem, tid, ra);
   store_tile<!TB_KMAJOR>(smem + OP_STAGE_BYTES, tid, rb);
   __syncthreads();
@@ -197,11 +225,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, ch
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = FMT == 1 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, bfr[j]), __builtin_bit_cast(h8, af[i]), acc[i][j], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
     if (t + 1 < nk) {
-      if (XF == 1) xform_tile<TA>(p, m0, p.M, kbeg + (t + 1) * BK, kend, tid, ra, xg);
-      if (XF == 2) xform_tile<!TB_KMAJOR>(p, n0, p.N, kbeg + (t + 1) * BK, kend, tid, rb, xg);
+      if (XF == 1) xform_tile<TA, FMT>(p, m0, p.M, kbeg + (t + 1) * BK, kend, tid, ra, xg);
+      if (XF == 2) xform_tile<!TB_KMAJOR, FMT>(p, n0, p.N, kbeg + (t + 1) * BK, kend, tid, rb, xg);
+      if (FMT == 2 && XF == 0) convert_tile_f16_bf16(rb);
       char* na = smem + (cur ^ 1) * STAGE_BYTES;
       store_tile<TA>(na, tid, ra);
       store_tile<!TB_KMAJOR>(na + OP_STAGE_BYTES, tid, rb);
@@ -216,7 +246,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, ch
     float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
     if (p.stats) {                     // launch-uniform: bf16 output + BatchNorm column statistics of this M-tile
       float cs[4], cq[4];
-      stats_epilogue(p, acc, row0, col0, lane, stg, cs, cq);
+      stats_epilogue<FMT == 1>(p, acc, row0, col0, lane, stg, cs, cq);
       __syncthreads();                 // all staging reads done: the region is reused for the cross-wave sum
       float* red = reinterpret_cast<float*>(smem);          // [wave][2][64]
       if (lane < 16) {
@@ -234,6 +264,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, ch
       }
       return;
     }
+    if (FMT == 1 && !p.c_f32) { f16_epilogue(p, acc, row0, col0, lane, stg); return; }
     if (!p.c_f32) fast_epilogue_epi<0, true>(p, acc, row0, col0, lane, fs, stg);
     else if (p.atomic) fast_epilogue<EPI_NONE, 3, true>(p, acc, row0, col0, lane, fs, stg);
     else if (p.accum && p.epi == EPI_ROWFIX) fast_epilogue<EPI_ROWFIX, 2, true>(p, acc, row0, col0, lane, fs, stg);
@@ -245,22 +276,22 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, ch
   }
 }
 
-template <bool TA, bool TB_KMAJOR, int XF = 0>
+template <bool TA, bool TB_KMAJOR, int XF = 0, int FMT = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm_body<TA, TB_KMAJOR, XF>(p, blockIdx.x, smem);
+  gemm_body<TA, TB_KMAJOR, XF, FMT>(p, blockIdx.x, smem);
 }
 
 // Two products of one layer's backward in ONE launch: the weight gradient (A^T B, split-K; XF = 2 applies the operand transform
 // to B) in blocks [0, nwg1) and the data gradient (A B, bf16 output with its epilogue) in blocks [n1r, n1r + nwg2), n1r = nwg1
 // rounded up to 8.  At 14 x 14 / 7 x 7 each of them alone runs 1.3-2.5 rounds of tiles on the chip; together the data
 // gradient's short blocks fill the tail of the weight gradient's long ones, and a layer issues one launch instead of two.
-template <int XF>
+template <int XF, int FMT1 = 0>      // FMT1: format of the weight-gradient product (2: its activation operand is fp16); the data gradient is bf16
 __global__ __launch_bounds__(256, 2) void gemm_bwd_pair_kernel(GemmParams p1, GemmParams p2, int nwg1, int n1r) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = blockIdx.x;
   if (bid < n1r) {
-    if (bid < nwg1) gemm_body<true, false, XF>(p1, bid, smem);
+    if (bid < nwg1) gemm_body<true, false, XF, FMT1>(p1, bid, smem);
   } else {
     gemm_body<false, false, 0>(p2, bid - n1r, smem);
   }
@@ -290,15 +321,17 @@ static int group_flush() {
   if (n == 2) {
     const GroupItem &a = g.item[0], &b = g.item[1];
     const bool wgrad_first = a.trans_a && !a.b_kmajor && (a.xf == 0 || a.xf == 2);
-    const bool dgrad_second = !b.trans_a && !b.b_kmajor && b.xf == 0;
-    if (wgrad_first && dgrad_second && a.s == b.s) {
+    const bool dgrad_second = !b.trans_a && !b.b_kmajor && b.xf == 0 && b.p.fmt == 0;
+    if (wgrad_first && dgrad_second && a.s == b.s && (a.p.fmt == 0 || a.p.fmt == 2)) {
       hipStream_t s = a.s;
       generic_attr_optin();
       const int n1r = (a.nwg + 7) & ~7;
       dim3 grid(n1r + b.nwg), block(256);
       const size_t lds = 2 * STAGE_BYTES;
-      if (a.xf == 2) hipLaunchKernelGGL((gemm_bwd_pair_kernel<2>), grid, block, lds, s, a.p, b.p, a.nwg, n1r);
-      else hipLaunchKernelGGL((gemm_bwd_pair_kernel<0>), grid, block, lds, s, a.p, b.p, a.nwg, n1r);
+      if (a.xf == 2 && a.p.fmt == 2) hipLaunchKernelGGL((gemm_bwd_pair_kernel<2, 2>), grid, block, lds, s, a.p, b.p, a.nwg, n1r);
+      else if (a.xf == 2) hipLaunchKernelGGL((gemm_bwd_pair_kernel<2, 0>), grid, block, lds, s, a.p, b.p, a.nwg, n1r);
+      else if (a.p.fmt == 2) hipLaunchKernelGGL((gemm_bwd_pair_kernel<0, 2>), grid, block, lds, s, a.p, b.p, a.nwg, n1r);
+      else hipLaunchKernelGGL((gemm_bwd_pair_kernel<0, 0>), grid, block, lds, s, a.p, b.p, a.nwg, n1r);
       return mmsim_check_launch("gemm_bwd_pair");
     }
   }
@@ -314,8 +347,12 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
                      int ldb, void* C, int ldc, int c_is_f32, const float* bias, int epilogue,
                      const void* aux_in, void* aux_out, int ld_aux, float alpha, int split_k,
                      int accumulate, int xf_operand, const float* xf_scale, const float* xf_shift, const float* xf_gate,
-                     int xf_hw, void* stream, float* stats = nullptr, float* colsum = nullptr) {
+                     int xf_hw, void* stream, float* stats = nullptr, float* colsum = nullptr, int fmt = 0) {
   MMSIM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: M, N, K must be positive");
+  MMSIM_REQUIRE(fmt >= 0 && fmt <= 2, "gemm: fmt must be 0 (bf16), 1 (fp16 operands) or 2 (fp16 B converted to bf16)");
+  MMSIM_REQUIRE(fmt != 1 || (!trans_a && b_kmajor && xf_operand != 2 && split_k == 1 && (c_is_f32 || (epilogue == EPI_NONE && !bias))),
+                "gemm: fmt 1 is the forward layout only (A, B k-major, no split-K); an fp16 output takes no bias / epilogue");
+  MMSIM_REQUIRE(fmt != 2 || (trans_a && !b_kmajor && xf_operand != 1 && c_is_f32), "gemm: fmt 2 is the weight-gradient layout only (A^T B, f32 output)");
   MMSIM_REQUIRE(A && B && C, "gemm: null operand");
   MMSIM_REQUIRE((lda % 8) == 0 && (ldb % 8) == 0, "gemm: lda/ldb must be multiples of 8 elements (16-byte rows)");
   MMSIM_REQUIRE((ldc % 4) == 0, "gemm: ldc must be a multiple of 4");
@@ -342,7 +379,7 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   p.c_f32 = c_is_f32; p.epi = epilogue; p.atomic = split_k > 1; p.accum = accumulate; p.alpha = alpha;
   p.xf_scale = xf_scale; p.xf_shift = xf_shift; p.xf_gate = xf_gate; p.xf_hw = xf_hw > 0 ? xf_hw : 1; p.xf_dhw = make_fastdiv(p.xf_hw);
   p.xf_C = (xf_operand == 1) ? K : N;
-  p.stats = stats; p.band = 1; p.colsum = colsum;
+  p.stats = stats; p.band = 1; p.colsum = colsum; p.fmt = fmt;
 #ifdef MMSIM_ABLATE     // ablation object only (tools/bench_gemm_abl.py); the product library never reads this variable
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MMSIM_GEMM_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
 #else
@@ -357,9 +394,9 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   dim3 grid(p.tiles_m * p.tiles_n * splits), block(256);
   const size_t lds = 2 * STAGE_BYTES;
   hipStream_t s = (hipStream_t)stream;
-  MMSIM_REQUIRE(!colsum || (trans_a && !b_kmajor && xf_operand == 0 && !stats && !force_generic() && gemm_fast_eligible(p, splits)),
+  MMSIM_REQUIRE(!colsum || (trans_a && !b_kmajor && xf_operand == 0 && !stats && fmt == 0 && !force_generic() && gemm_fast_eligible(p, splits)),
                 "gemm: the fused column sum needs the pipelined weight-gradient kernel");
-  if (xf_operand == 0 && !stats && !force_generic() && gemm_fast_eligible(p, splits)) {
+  if (xf_operand == 0 && !stats && fmt == 0 && !force_generic() && gemm_fast_eligible(p, splits)) {
     if (g_group.active) { const int rc = group_flush(); if (rc) return rc; }
     gemm_fast_launch(p, trans_a, b_kmajor, splits, s);
     return mmsim_check_launch("gemm_bf16_fast");
@@ -387,8 +424,14 @@ static void generic_attr_optin() {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_bwd_pair_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_bwd_pair_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bwd_pair_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bwd_pair_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bwd_pair_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bwd_pair_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done |= 1ull << dev;
   }
 }
@@ -397,7 +440,13 @@ static int launch_generic(const GemmParams& p, int trans_a, int b_kmajor, int xf
   generic_attr_optin();
   const size_t lds = 2 * STAGE_BYTES;
   dim3 grid(nwg), block(256);
-  if (xf_operand == 1) {
+  if (p.fmt == 1) {                // fp16 forward products (gemm_impl checked the layout)
+    if (xf_operand == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false, true, 1, 1>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<false, true, 0, 1>), grid, block, lds, s, p);
+  } else if (p.fmt == 2) {         // weight gradients with an fp16 activation operand
+    if (xf_operand == 2) hipLaunchKernelGGL((gemm_bf16_kernel<true, false, 2, 2>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false, 0, 2>), grid, block, lds, s, p);
+  } else if (xf_operand == 1) {
     hipLaunchKernelGGL((gemm_bf16_kernel<false, true, 1>), grid, block, lds, s, p);
   } else if (xf_operand == 2) {
     hipLaunchKernelGGL((gemm_bf16_kernel<true, false, 2>), grid, block, lds, s, p);
@@ -459,6 +508,16 @@ extern "C" int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, c
                    alpha, split_k, accumulate, 0, nullptr, nullptr, nullptr, 1, stream);
 }
 
+// The same product with an explicit element format (GemmParams::fmt): 1 = fp16 A, B (and C unless f32), forward layout only;
+// 2 = weight gradient whose B operand (the activation) is fp16 and is converted to bf16 while staged; 0 = mmsim_gemm_bf16.
+extern "C" int mmsim_gemm_fmt(int fmt, int trans_a, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B,
+                              int ldb, void* C, int ldc, int c_is_f32, const float* bias, int epilogue,
+                              const void* aux_in, void* aux_out, int ld_aux, float alpha, int split_k,
+                              int accumulate, void* stream) {
+  return gemm_impl(trans_a, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, c_is_f32, bias, epilogue, aux_in, aux_out, ld_aux,
+                   alpha, split_k, accumulate, 0, nullptr, nullptr, nullptr, 1, stream, nullptr, nullptr, fmt);
+}
+
 // 1x1 conv whose input is silu(scale*z + shift) * gate[pixel / hw, channel] applied on the fly while staging:
 //   xf_operand = 1: forward   C[P, Cout] = xf(A)[P, Cin] * B[Cout, Cin]^T        (A k-major, B k-major)
 //   xf_operand = 2: wgrad     C[Cout, Cin] (+)= A[P, Cout]^T * xf(B)[P, Cin]      (both stored [P][.])
@@ -469,7 +528,7 @@ extern "C" int mmsim_gemm_bf16_xf(int xf_operand, int M, int N, int K, const voi
   MMSIM_REQUIRE((xf_scale && xf_shift) || (!xf_scale && !xf_shift && xf_gate), "gemm_xf: scale and shift, or neither with a gate (gate-only operand)");
   MMSIM_REQUIRE(((xf_operand == 1 ? K : N) % 8) == 0, "gemm_xf: transformed channel count must be a multiple of 8");
   return gemm_impl(xf_operand == 2, xf_operand == 1, M, N, K, A, lda, B, ldb, C, ldc, c_is_f32, nullptr, 0, nullptr, nullptr, 0,
-                   1.0f, split_k, accumulate, xf_operand, xf_scale, xf_shift, xf_gate, xf_hw, stream);
+                   1.0f, split_k, accumulate, xf_operand, xf_scale, xf_shift, xf_gate, xf_hw, stream, nullptr, nullptr, xf_operand);
 }
 
 void mmsim_launch_reduce(const float* parts, int nparts, int n, float* out, int accumulate, hipStream_t s);   // conv.hip
@@ -486,7 +545,7 @@ extern "C" int mmsim_gemm_bf16_bnstats(int xf_operand, int M, int N, int K, cons
   const int tiles_m = (M + BM - 1) / BM;
   MMSIM_REQUIRE(scratch && (unsigned long long)tiles_m * 2 * N <= scratch_floats, "gemm_bnstats: scratch too small (need ceil(M/128)*2*N floats)");
   const int rc = gemm_impl(0, 1, M, N, K, A, lda, B, ldb, C, ldc, 0, nullptr, 0, nullptr, nullptr, 0, 1.0f, 1, 0, xf_operand,
-                           xf_scale, xf_shift, xf_gate, xf_hw, stream, scratch);
+                           xf_scale, xf_shift, xf_gate, xf_hw, stream, scratch, nullptr, 1);
   if (rc) return rc;
   mmsim_launch_reduce(scratch, tiles_m, 2 * N, sums, 1, (hipStream_t)stream);
   return mmsim_check_launch("gemm_bnstats");

@@ -19,6 +19,12 @@ struct GemmParams {
   // atomically into colsum[M] by the tile column 0 blocks -- the bias gradient of a dense layer out of its weight-gradient
   // product (A = dY), instead of a separate pass over dY (NULL = off)
   float* colsum;
+  // element format of the generic kernel's operands (gemm_bf16_kernel; the pipelined kernels are bf16 only):
+  //   0  bf16 A, B, bf16 / f32 C
+  //   1  fp16 A, B, fp16 / f32 C, v_mfma_f32_16x16x32_f16 (image-tower forward: activations and the weight shadow are fp16)
+  //   2  bf16 A, fp16 B converted to bf16 while it is staged, f32 C (image-tower weight gradients: A = the bf16 gradient, B = the
+  //      fp16 activation)
+  int fmt;
   int dbg;   // ablation object only (-DMMSIM_ABLATE): 1 no DMA, 4 no MFMA, 8 no epilogue; the product build ignores it
 };
 
@@ -171,6 +177,7 @@ __device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][
 // bf16 store of a 64x64 sub-tile (no bias / activation: the 1x1 convs) that also returns the column sums of the ROUNDED
 // outputs -- the train-mode BatchNorm statistics of the conv output, so no separate pass re-reads it.
 // cs / cq: lanes 0..15 end up with sum / sum of squares of columns col0 + 4*(lane&15) + {0..3} over this wave's valid rows.
+template <bool F16 = false>
 __device__ __forceinline__ void stats_epilogue(const GemmParams& p, f4 (&acc)[4][4], int row0, int col0, int lane, float* tile,
                                                float (&cs)[4], float (&cq)[4]) {
 #pragma unroll
@@ -187,6 +194,13 @@ __device__ __forceinline__ void stats_epilogue(const GemmParams& p, f4 (&acc)[4]
       const int r = it * 4 + (lane >> 4);
       if (row0 + r >= p.M) continue;
       const f4 a = *reinterpret_cast<const f4*>(tile + r * EP_PITCH + c4);
+      if (F16) {
+        h4 o = {f2h(a[0] * p.alpha), f2h(a[1] * p.alpha), f2h(a[2] * p.alpha), f2h(a[3] * p.alpha)};
+        *reinterpret_cast<h4*>(reinterpret_cast<f16*>(p.C) + (size_t)(row0 + r) * p.ldc + n) = o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float v = h2f(o[e]); cs[e] += v; cq[e] += v * v; }
+        continue;
+      }
       bf4 o = {f2bf(a[0] * p.alpha), f2bf(a[1] * p.alpha), f2bf(a[2] * p.alpha), f2bf(a[3] * p.alpha)};
       *reinterpret_cast<bf4*>(reinterpret_cast<bf16*>(p.C) + (size_t)(row0 + r) * p.ldc + n) = o;
 #pragma unroll
@@ -197,6 +211,31 @@ __device__ __forceinline__ void stats_epilogue(const GemmParams& p, f4 (&acc)[4]
   for (int e = 0; e < 4; ++e) {
     cs[e] += __shfl_xor(cs[e], 16, 64); cs[e] += __shfl_xor(cs[e], 32, 64);
     cq[e] += __shfl_xor(cq[e], 16, 64); cq[e] += __shfl_xor(cq[e], 32, 64);
+  }
+}
+
+// fp16 store of a 64x64 sub-tile, ragged tiles predicated, no bias / activation (fmt 1 without the statistics: the 1x1 convs of
+// the image tower in tests and eval-side callers); N % 4 == 0 is the host's contract (ldc % 4), columns are checked per group
+__device__ __forceinline__ void f16_epilogue(const GemmParams& p, f4 (&acc)[4][4], int row0, int col0, int lane, float* tile) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f4*>(tile + (i * 16 + (lane & 15)) * EP_PITCH + j * 16 + (lane >> 4) * 4) = acc[i][j];
+  const int c4 = (lane & 15) * 4, n = col0 + c4;
+  if (n >= p.N) return;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int r = it * 4 + (lane >> 4);
+    if (row0 + r >= p.M) continue;
+    const f4 a = *reinterpret_cast<const f4*>(tile + r * EP_PITCH + c4);
+    f16* c = reinterpret_cast<f16*>(p.C) + (size_t)(row0 + r) * p.ldc + n;
+    if (n + 3 < p.N) {
+      h4 o = {f2h(a[0] * p.alpha), f2h(a[1] * p.alpha), f2h(a[2] * p.alpha), f2h(a[3] * p.alpha)};
+      *reinterpret_cast<h4*>(c) = o;
+    } else {
+      for (int e = 0; e < 4 && n + e < p.N; ++e) c[e] = f2h(a[e] * p.alpha);
+    }
   }
 }
 

@@ -219,6 +219,16 @@ __global__ void cast_f32_bf16_kernel(const float* x, bf16* y, size_t n) {
   }
   if (i < n) for (size_t k = i; k < n && k < i + 4; ++k) y[k] = f2bf(x[k]);
 }
+__global__ void cast_f32_f16_kernel(const float* x, f16* y, size_t n) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    h4 o = {f2h(v.x), f2h(v.y), f2h(v.z), f2h(v.w)};
+    *reinterpret_cast<h4*>(y + i) = o;
+  }
+  if (i < n) for (size_t k = i; k < n && k < i + 4; ++k) y[k] = f2h(x[k]);
+}
 __global__ void cast_bf16_f32_kernel(const bf16* x, float* y, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -243,7 +253,7 @@ __global__ void tanh_bwd_kernel(const float* dpooled, const float* pooled, bf16*
 
 // ---------------------------------------------------------------- fused AdamW over a flat buffer
 // p <- p(1 - lr wd); m <- b1 m + (1-b1) g; v <- b2 v + (1-b2) g^2; p <- p - (lr/bc1) m / (sqrt(v)/sqrt(bc2) + eps)
-__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16* shadow, size_t n,
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16* shadow, f16* shadow16, size_t n,
                                                     float lr, float b1, float b2, float eps, float wd, float bc1,
                                                     float rsqrt_bc2, float gscale, const float* hyper) {
   if (hyper) { lr = hyper[0]; bc1 = hyper[1]; rsqrt_bc2 = hyper[2]; }      // step-dependent scalars from device memory (graph replay)
@@ -272,6 +282,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
     if (shadow) {
       bf4 o = {f2bf(P[0]), f2bf(P[1]), f2bf(P[2]), f2bf(P[3])};
       __builtin_nontemporal_store(o, reinterpret_cast<bf4*>(shadow + i));
+    }
+    if (shadow16) {      // the image tower's forward products read their weights as fp16 (common.h)
+      h4 o = {f2h(P[0]), f2h(P[1]), f2h(P[2]), f2h(P[3])};
+      __builtin_nontemporal_store(o, reinterpret_cast<h4*>(shadow16 + i));
     }
   }
 }
@@ -451,6 +465,12 @@ extern "C" int mmsim_cast_f32_to_bf16(const float* x, void* y, unsigned long lon
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)y, (size_t)n);
   return mmsim_check_launch("cast_f32_to_bf16");
 }
+extern "C" int mmsim_cast_f32_to_f16(const float* x, void* y, unsigned long long n, void* stream) {
+  MMSIM_REQUIRE(x && y, "cast: null");
+  if (n == 0) return MMSIM_OK;
+  hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, (f16*)y, (size_t)n);
+  return mmsim_check_launch("cast_f32_to_f16");
+}
 extern "C" int mmsim_cast_bf16_to_f32(const void* x, float* y, unsigned long long n, void* stream) {
   MMSIM_REQUIRE(x && y, "cast: null");
   if (n == 0) return MMSIM_OK;
@@ -474,15 +494,23 @@ extern "C" int mmsim_tanh_bwd(const float* dpooled, const float* pooled, void* d
   return mmsim_check_launch("tanh_bwd");
 }
 
+extern "C" int mmsim_adamw_step2(float* p, const float* g, float* m, float* v, void* bf16_shadow, void* f16_shadow, unsigned long long n,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                 float grad_scale, const float* dev_hyper, void* stream);
 extern "C" int mmsim_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, unsigned long long n,
                                 float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                 float grad_scale, const float* dev_hyper, void* stream) {
+  return mmsim_adamw_step2(p, g, m, v, bf16_shadow, nullptr, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, dev_hyper, stream);
+}
+extern "C" int mmsim_adamw_step2(float* p, const float* g, float* m, float* v, void* bf16_shadow, void* f16_shadow, unsigned long long n,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                 float grad_scale, const float* dev_hyper, void* stream) {
   MMSIM_REQUIRE(p && g && m && v, "adamw: null operand");
   MMSIM_REQUIRE(n % 4 == 0, "adamw: flat buffer length must be a multiple of 4");
   MMSIM_REQUIRE(step >= 1, "adamw: step is 1-based");
   if (n == 0) return MMSIM_OK;
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)bf16_shadow,
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)bf16_shadow, (f16*)f16_shadow,
                      (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, dev_hyper);
   return mmsim_check_launch("adamw");
 }

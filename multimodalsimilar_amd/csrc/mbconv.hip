@@ -1,4 +1,6 @@
-// LDS-tiled depthwise-convolution kernels of the MBConv block for gfx950 (NHWC bf16 activations, fp32 arithmetic).
+// LDS-tiled depthwise-convolution kernels of the MBConv block for gfx950 (NHWC activations, fp32 arithmetic).
+// Element types as in conv.hip: FORWARD tensors (z1, z2, a2, z3, x and the 1x1-conv weight shadow the forward products read) are
+// fp16, GRADIENT tensors (dy, dz, dx, resid) and the weight shadow the data-gradient products read are bf16.
 //
 // The round-1 depthwise kernels (conv.hip) read every input row straight from global memory once per kernel row: a 5x5
 // output strip issues 40 16-byte loads for 4 outputs and the vector-memory path, not HBM, set their rate (1.6-2.8 TB/s).
@@ -60,15 +62,27 @@ template <> __device__ __forceinline__ uint2 packN<4>(const float (&f)[4]) {
   for (int e = 0; e < 4; ++e) b[e] = f2bf(f[e]);
   return __builtin_bit_cast(uint2, b);
 }
+// fp16 chunks (forward tensors)
+__device__ __forceinline__ void unpack8h(const uint4& v, float (&f)[8]) {
+  const h8 b = __builtin_bit_cast(h8, v);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = h2f(b[e]);
+}
+__device__ __forceinline__ uint4 pack8h(const float (&f)[8]) {
+  h8 b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) b[e] = f2h(f[e]);
+  return __builtin_bit_cast(uint4, b);
+}
 // bounds-masked load: the address is always valid (callers clamp), the value is AND-masked (a select of a load makes hipcc
 // branch around it and wait vmcnt(0) per element, conv.hip)
-template <int CPT> __device__ __forceinline__ typename UnitT<CPT>::T ldN_masked(const bf16* p, bool ok);
-template <> __device__ __forceinline__ uint4 ldN_masked<8>(const bf16* p, bool ok) {
+template <int CPT> __device__ __forceinline__ typename UnitT<CPT>::T ldN_masked(const void* p, bool ok);
+template <> __device__ __forceinline__ uint4 ldN_masked<8>(const void* p, bool ok) {
   const uint4 v = *reinterpret_cast<const uint4*>(p);
   const unsigned int m = ok ? 0xffffffffu : 0u;
   return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
 }
-template <> __device__ __forceinline__ uint2 ldN_masked<4>(const bf16* p, bool ok) {
+template <> __device__ __forceinline__ uint2 ldN_masked<4>(const void* p, bool ok) {
   const uint2 v = *reinterpret_cast<const uint2*>(p);
   const unsigned int m = ok ? 0xffffffffu : 0u;
   return make_uint2(v.x & m, v.y & m);
@@ -103,8 +117,8 @@ __device__ __forceinline__ void lanes_reduce(float (&acc)[NV], float* red, int u
 
 // ------------------------------------------------------------------ forward
 template <int K, int S, bool XF>
-__global__ __launch_bounds__(256, 3) void dwt_fwd_kernel(const bf16* in, const float* scale, const float* shift, const float* wT,
-                                                         bf16* out, float* parts, DwTile g) {
+__global__ __launch_bounds__(256, 3) void dwt_fwd_kernel(const f16* in, const float* scale, const float* shift, const float* wT,
+                                                         f16* out, float* parts, DwTile g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PAD = K / 2, NIN = 3 * S + K;
   const int tid = threadIdx.x;
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(256, 3) void dwt_fwd_kernel(const bf16* in, const f
     if (lane_ok) {
       float sc[8], sh[8];                 // per-phase loads: the channel vectors do not occupy registers across the tap loop
       if (XF) { ldNf<8>(scale + c0, sc); ldNf<8>(shift + c0, sh); }
-      const bf16* inb = in + (size_t)b * g.Hi * g.Wi * g.C + c0;
+      const f16* inb = in + (size_t)b * g.Hi * g.Wi * g.C + c0;
       for (int i0 = pl; i0 < npix; i0 += 4 * g.NP) {       // four pixels per trip: all loads requested before the first use
         uint4 v[4];
         bool ok[4];
@@ -152,15 +166,15 @@ __global__ __launch_bounds__(256, 3) void dwt_fwd_kernel(const bf16* in, const f
         for (int q = 0; q < 4; ++q) {
           const int i = i0 + q * g.NP;
           if (i < npix) {
-            if (XF) {       // a1 = silu(bn(z1)), rounded to bf16 as the stored tensor was; padding is zero AFTER the activation
+            if (XF) {       // a1 = silu(bn(z1)), staged as fp16; padding is zero AFTER the activation
               // a real branch, not a select: under a 5 x 5 window 40-60 % of a 14^2 / 7^2 tile's staged pixels are padding, and a
               // wave whose pixels are all outside the image skips the transcendentals altogether
               if (ok[q]) {
                 float f[8];
-                unpackN<8>(v[q], f);
+                unpack8h(v[q], f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e] * sc[e] + sh[e]);
-                v[q] = packN<8>(f);
+                v[q] = pack8h(f);
               } else {
                 v[q] = make_uint4(0, 0, 0, 0);
               }
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(256, 3) void dwt_fwd_kernel(const bf16* in, const f
 #if DWT_ROW_UNPACK
           float xin[NIN][8];
 #pragma unroll
-          for (int x = 0; x < NIN; ++x) unpackN<8>(row[(size_t)x * g.OG], xin[x]);
+          for (int x = 0; x < NIN; ++x) unpack8h(row[(size_t)x * g.OG], xin[x]);
 #pragma unroll
           for (int kw = 0; kw < K; ++kw) {
             float w[8];
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(256, 3) void dwt_fwd_kernel(const bf16* in, const f
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               float xin[8];
-              unpackN<8>(raw[j * S + kw], xin);
+              unpack8h(raw[j * S + kw], xin);
 #pragma unroll
               for (int e = 0; e < 8; ++e) acc[j][e] += xin[e] * w[e];
             }
@@ -220,10 +234,10 @@ __global__ __launch_bounds__(256, 3) void dwt_fwd_kernel(const bf16* in, const f
         for (int j = 0; j < 4; ++j) {
           const int gx = ox0 + sx * 4 + j;
           if (cok && gy < g.Ho && gx < g.Wo) {
-            const uint4 o = packN<8>(acc[j]);
+            const uint4 o = pack8h(acc[j]);
             *reinterpret_cast<uint4*>(out + (((size_t)b * g.Ho + gy) * g.Wo + gx) * g.C + c0) = o;
             float r[8];
-            unpackN<8>(o, r);
+            unpack8h(o, r);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { st[e] += r[e]; st[8 + e] += r[e] * r[e]; }
           }
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(256, 3) void dwt_fwd_kernel(const bf16* in, const f
 
 // ------------------------------------------------------------------ fused backward (stride 1)
 struct DwBwd {
-  const bf16* dy; const bf16* z2; const bf16* z1; const bf16* resid;
+  const bf16* dy; const f16* z2; const f16* z1; const bf16* resid;      // z1: the depthwise conv's input (z1 of an IR block, x of a DS block)
   const float* sc2; const float* sh2; const float* mu2; const float* rs2; const float* sums2;     // depthwise BatchNorm
   const float* gate; const float* dsq;                                                              // [B, C] fp32
   const float* sc1; const float* sh1; const float* mu1; const float* rs1;                          // expand BatchNorm (IR blocks)
@@ -340,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
             uint4 ov = make_uint4(0, 0, 0, 0);
             if (ok[q]) {      // a real branch: waves whose pixels are all padding skip the arithmetic (see dwt_fwd_kernel)
               float d[8], z[8], o[8];
-              unpackN<8>(vd[q], d); unpackN<8>(vz[q], z);
+              unpackN<8>(vd[q], d); unpack8h(vz[q], z);
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
                 const float da = (d[e] * gs[e] + qs[e]) * silu_grad_f(z[e] * sc2[e] + sh2[e]);
@@ -415,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
 #pragma unroll
         for (int j = 0; j < SW; ++j) {
           float z[8], a1[8], o[8];
-          unpackN<8>(zr[j], z);
+          unpack8h(zr[j], z);
           if (PLAIN) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { a1[e] = z[e]; o[e] = da[j][e]; }          // masked load: zero outside the image
@@ -441,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
               for (int e = 0; e < 8; ++e) { st[e] += o[e]; st[8 + e] += o[e] * (z[e] - mu1[e]) * rs1[e]; }
             }
           }
-          cen[(size_t)(oy * g.TW + sx * SW + j) * g.OG + u] = packN<8>(a1);       // the rounded a1 the forward convolved
+          cen[(size_t)(oy * g.TW + sx * SW + j) * g.OG + u] = pack8h(a1);       // the rounded (fp16) a1 the forward convolved
         }
       }
     }
@@ -464,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
 #pragma unroll
           for (int j = 0; j < SW; ++j) {
             float a[8];
-            unpackN<8>(ra[j], a);
+            unpack8h(ra[j], a);
 #pragma unroll
             for (int kw = 0; kw < K; ++kw)
 #pragma unroll
@@ -474,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
 #pragma unroll
           for (int j = 0; j < SW; ++j) {
             float a[8];
-            unpackN<8>(ra[j], a);
+            unpack8h(ra[j], a);
 #pragma unroll
             for (int kw = 0; kw < K; ++kw) {
               float tv[8];
@@ -602,7 +616,7 @@ extern "C" int mmsim_dwtile_fwd(const void* in, const float* xf_scale, const flo
   int rc = make_geom(&g, B, Hi, Wi, C, K, S, false, xf_scale != nullptr, &lds, &grid); if (rc) return rc;
   MMSIM_REQUIRE(scratch_floats >= (unsigned long long)grid.x * 2 * C, "dwtile_fwd: scratch too small");
   hipStream_t s = (hipStream_t)stream;
-#define DWT_F(KK, SS, XX) hipLaunchKernelGGL((dwt_fwd_kernel<KK, SS, XX>), grid, dim3(256), lds, s, (const bf16*)in, xf_scale, xf_shift, w_tap_major, (bf16*)z, scratch, g)
+#define DWT_F(KK, SS, XX) hipLaunchKernelGGL((dwt_fwd_kernel<KK, SS, XX>), grid, dim3(256), lds, s, (const f16*)in, xf_scale, xf_shift, w_tap_major, (f16*)z, scratch, g)
 #define DWT_FX(XX)                                                                        \
   if (K == 3 && S == 1) DWT_F(3, 1, XX); else if (K == 3 && S == 2) DWT_F(3, 2, XX);     \
   else if (K == 5 && S == 1) DWT_F(5, 1, XX); else DWT_F(5, 2, XX);
@@ -629,7 +643,7 @@ extern "C" int mmsim_dwtile_bwd(const void* dy, const void* z2, const float* sca
   const size_t n_bn = plain ? 0 : (size_t)grid.x * 2 * C, n_w = (size_t)grid.x * K * K * C;
   MMSIM_REQUIRE(scratch_floats >= (unsigned long long)(n_bn + n_w), "dwtile_bwd: scratch too small");
   DwBwd p;
-  p.dy = (const bf16*)dy; p.z2 = (const bf16*)z2; p.z1 = (const bf16*)z1; p.resid = (const bf16*)resid;
+  p.dy = (const bf16*)dy; p.z2 = (const f16*)z2; p.z1 = (const f16*)z1; p.resid = (const bf16*)resid;
   p.sc2 = scale2; p.sh2 = shift2; p.mu2 = mean2; p.rs2 = rstd2; p.sums2 = sums2; p.gate = gate; p.dsq = dsq;
   p.sc1 = scale1; p.sh1 = shift1; p.mu1 = mean1; p.rs1 = rstd1; p.wT = w_tap_major; p.out = (bf16*)out;
   p.parts_bn = scratch; p.parts_w = scratch + n_bn; p.dgamma2 = dgamma2; p.dbeta2 = dbeta2;
@@ -658,7 +672,7 @@ extern "C" int mmsim_dwtile_bwd(const void* dy, const void* z2, const float* sca
 // over the widest tensors of the tower.  Only where W1 and dW1 are small enough to live in LDS / registers -- mid <= 352,
 // cin <= 64: stages 1-2, which is where those tensors exceed the 256 MB Infinity Cache and every pass is an HBM pass.
 struct PwBwd {
-  const bf16* dpre; const bf16* z1; const bf16* x; const bf16* resid; const bf16* w1;
+  const bf16* dpre; const f16* z1; const f16* x; const bf16* resid; const bf16* w1;      // w1: the bf16 weight shadow
   const float* sc1; const float* mu1; const float* rs1; const float* sums1;
   bf16* dx; float* parts; float* dgamma; float* dbeta;
   int P, mid, cin, nstrips, KS;      // KS = ceil(mid / 32)
@@ -667,6 +681,10 @@ struct PwBwd {
 
 __device__ __forceinline__ f4 mfma16(bf8 first, bf8 second, f4 acc) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(first, second, acc, 0, 0, 0);      // acc[e] = C[second row lane&15][first row 4(lane>>4)+e]
+}
+
+__device__ __forceinline__ f4 mfma16h(h8 first, h8 second, f4 acc) {      // the same tile shape on fp16 operands (forward products)
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(first, second, acc, 0, 0, 0);
 }
 
 template <int BM, int CIN_T, int MAXW, int NTHR = 256, int NCH = 6>
@@ -719,11 +737,12 @@ __global__ __launch_bounds__(NTHR) void pw_expand_bwd_kernel(PwBwd p) {
       const int q = tid + NTHR * i;
       if (q < nchunks) {
         const int pix = q / G, un = q - pix * G;
-        const bf8 d = __builtin_bit_cast(bf8, vd[i]), z = __builtin_bit_cast(bf8, vz[i]);
+        const bf8 d = __builtin_bit_cast(bf8, vd[i]);
+        const h8 z = __builtin_bit_cast(h8, vz[i]);
         const float* cs = cst + un * 8;
         bf8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(cs[e] * bf2f(d[e]) - cs[p.mid + e] - bf2f(z[e]) * cs[2 * p.mid + e]);
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(cs[e] * bf2f(d[e]) - cs[p.mid + e] - h2f(z[e]) * cs[2 * p.mid + e]);
         *reinterpret_cast<bf8*>(zimg + pix * ZP + un * 16) = o;
       }
     }
@@ -731,8 +750,12 @@ __global__ __launch_bounds__(NTHR) void pw_expand_bwd_kernel(PwBwd p) {
       const int xg = p.cin >> 3;
       for (int q = tid; q < BM * xg; q += NTHR) {
         const int pix = q / xg, un = q - pix * xg;
-        *reinterpret_cast<uint4*>(ximg + pix * XP + un * 16) =
-            *reinterpret_cast<const uint4*>(p.x + ((size_t)strip * BM + pix) * p.cin + un * 8);
+        // x is fp16 in HBM; the weight-gradient MFMA pairs it with the bf16 dz1 image, so it is staged as bf16
+        const h8 xv = *reinterpret_cast<const h8*>(p.x + ((size_t)strip * BM + pix) * p.cin + un * 8);
+        bf8 xo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xo[e] = f2bf(h2f(xv[e]));
+        *reinterpret_cast<bf8*>(ximg + pix * XP + un * 16) = xo;
       }
     }
     __syncthreads();
@@ -821,7 +844,7 @@ static int launch_pw_expand_bwd(PwBwd p, float* dw1, hipStream_t s, float* scrat
 // reloaded when the range enters the next image) and written k-major into LDS; the 16 x 16 x 32 MFMAs read both operands with
 // plain 16-byte fragment reads.  Statistics stay in registers until the block ends (slab + mmsim_launch_reduce).
 struct PwPrj {
-  const bf16* a2; const float* gate; const bf16* w3; bf16* z3; float* parts;
+  const f16* a2; const float* gate; const f16* w3; f16* z3; float* parts;      // w3: the fp16 weight shadow
   const float* xsc; const float* xsh;      // non-NULL: `a2` is the pre-BatchNorm tensor z2 and the operand is silu(xsc z2 + xsh) * gate
   int P, HW, B, mid, cout, nstrips, per_block, KS;
   FastDiv dhw;
@@ -889,17 +912,17 @@ __global__ __launch_bounds__(256) void pw_project_fwd_kernel(PwPrj p) {
       if (q < nchunks) {
         const int pix = q / G, un = q - pix * G;
         const float* gr = grow + (pix >= split ? p.mid : 0) + un * 8;
-        const bf8 a = __builtin_bit_cast(bf8, va[i]);
-        bf8 o;
+        const h8 a = __builtin_bit_cast(h8, va[i]);
+        h8 o;
         if (p.xsc) {      // launch-uniform: the activation is formed here, a2 is never stored
           const float* cs = xs + un * 8;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = f2bf(silu_f(bf2f(a[e]) * cs[e] + cs[p.mid + e]) * gr[e]);
+          for (int e = 0; e < 8; ++e) o[e] = f2h(silu_f(h2f(a[e]) * cs[e] + cs[p.mid + e]) * gr[e]);
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(a[e]) * gr[e]);
+          for (int e = 0; e < 8; ++e) o[e] = f2h(h2f(a[e]) * gr[e]);
         }
-        *reinterpret_cast<bf8*>(zimg + pix * ZP + un * 16) = o;
+        *reinterpret_cast<h8*>(zimg + pix * ZP + un * 16) = o;
       }
     }
     __syncthreads();
@@ -911,21 +934,21 @@ __global__ __launch_bounds__(256) void pw_project_fwd_kernel(PwPrj p) {
 #pragma unroll
       for (int n = 0; n < NT_W; ++n) acc[n] = f4{0.f, 0.f, 0.f, 0.f};
       for (int ks = 0; ks < p.KS; ++ks) {
-        const bf8 zf = *reinterpret_cast<const bf8*>(zimg + (mt * 16 + (lane & 15)) * ZP + (ks * 4 + (lane >> 4)) * 16);
+        const h8 zf = *reinterpret_cast<const h8*>(zimg + (mt * 16 + (lane & 15)) * ZP + (ks * 4 + (lane >> 4)) * 16);
 #pragma unroll
         for (int n = 0; n < NT_W; ++n) {
-          const bf8 wf = *reinterpret_cast<const bf8*>(wimg + ((nt0 + n) * 16 + (lane & 15)) * ZP + (ks * 4 + (lane >> 4)) * 16);
-          acc[n] = mfma16(wf, zf, acc[n]);                 // acc[e] = z3[pixel lane&15][channel 4(lane>>4)+e] of tile (mt, nt0+n)
+          const h8 wf = *reinterpret_cast<const h8*>(wimg + ((nt0 + n) * 16 + (lane & 15)) * ZP + (ks * 4 + (lane >> 4)) * 16);
+          acc[n] = mfma16h(wf, zf, acc[n]);                 // acc[e] = z3[pixel lane&15][channel 4(lane>>4)+e] of tile (mt, nt0+n)
         }
       }
       const int pix = mt * 16 + (lane & 15);
 #pragma unroll
       for (int n = 0; n < NT_W; ++n) {
         const int co = (nt0 + n) * 16 + (lane >> 4) * 4;
-        const bf4 o = {f2bf(acc[n][0]), f2bf(acc[n][1]), f2bf(acc[n][2]), f2bf(acc[n][3])};
-        if (co < p.cout) *reinterpret_cast<bf4*>(p.z3 + ((size_t)s0 + pix) * p.cout + co) = o;      // cout % 8 == 0: the group is valid as a whole
+        const h4 o = {f2h(acc[n][0]), f2h(acc[n][1]), f2h(acc[n][2]), f2h(acc[n][3])};
+        if (co < p.cout) *reinterpret_cast<h4*>(p.z3 + ((size_t)s0 + pix) * p.cout + co) = o;      // cout % 8 == 0: the group is valid as a whole
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float v = bf2f(o[e]); cs[n][e] += v; cq[n][e] += v * v; }   // zero weight rows past cout add zeros
+        for (int e = 0; e < 4; ++e) { const float v = h2f(o[e]); cs[n][e] += v; cq[n][e] += v * v; }   // zero weight rows past cout add zeros
       }
     }
   }
@@ -992,28 +1015,28 @@ static int pw_project_variant(int P, int HW, int mid, int cout) {
 }
 extern "C" int mmsim_pw_project_fwd_eligible(int P, int HW, int mid, int cout) { return pw_project_variant(P, HW, mid, cout) != 0; }
 
-static int pw_project_fwd_impl(const void* a2, const float* xf_scale, const float* xf_shift, const float* gate, const void* w3_bf16,
+static int pw_project_fwd_impl(const void* a2, const float* xf_scale, const float* xf_shift, const float* gate, const void* w3_f16,
                                void* z3, float* sums, int P, int HW, int mid, int cout, float* scratch,
                                unsigned long long scratch_floats, void* stream);
-extern "C" int mmsim_pw_project_fwd(const void* a2, const float* gate, const void* w3_bf16, void* z3, float* sums, int P, int HW,
+extern "C" int mmsim_pw_project_fwd(const void* a2, const float* gate, const void* w3_f16, void* z3, float* sums, int P, int HW,
                                     int mid, int cout, float* scratch, unsigned long long scratch_floats, void* stream) {
-  return pw_project_fwd_impl(a2, nullptr, nullptr, gate, w3_bf16, z3, sums, P, HW, mid, cout, scratch, scratch_floats, stream);
+  return pw_project_fwd_impl(a2, nullptr, nullptr, gate, w3_f16, z3, sums, P, HW, mid, cout, scratch, scratch_floats, stream);
 }
-extern "C" int mmsim_pw_project_fwd_xf(const void* z2, const float* xf_scale, const float* xf_shift, const float* gate, const void* w3_bf16,
+extern "C" int mmsim_pw_project_fwd_xf(const void* z2, const float* xf_scale, const float* xf_shift, const float* gate, const void* w3_f16,
                                        void* z3, float* sums, int P, int HW, int mid, int cout, float* scratch,
                                        unsigned long long scratch_floats, void* stream) {
   MMSIM_REQUIRE(xf_scale && xf_shift, "pw_project_fwd_xf: scale and shift required");
-  return pw_project_fwd_impl(z2, xf_scale, xf_shift, gate, w3_bf16, z3, sums, P, HW, mid, cout, scratch, scratch_floats, stream);
+  return pw_project_fwd_impl(z2, xf_scale, xf_shift, gate, w3_f16, z3, sums, P, HW, mid, cout, scratch, scratch_floats, stream);
 }
-static int pw_project_fwd_impl(const void* a2, const float* xf_scale, const float* xf_shift, const float* gate, const void* w3_bf16,
+static int pw_project_fwd_impl(const void* a2, const float* xf_scale, const float* xf_shift, const float* gate, const void* w3_f16,
                                void* z3, float* sums, int P, int HW, int mid, int cout, float* scratch,
                                unsigned long long scratch_floats, void* stream) {
-  MMSIM_REQUIRE(a2 && gate && w3_bf16 && z3 && sums && scratch, "pw_project_fwd: null operand");
+  MMSIM_REQUIRE(a2 && gate && w3_f16 && z3 && sums && scratch, "pw_project_fwd: null operand");
   const int v = pw_project_variant(P, HW, mid, cout);
   MMSIM_REQUIRE(v != 0, "pw_project_fwd: shape not eligible (see mmsim_pw_project_fwd_eligible)");
   PwPrj p;
   p.xsc = xf_scale; p.xsh = xf_shift;
-  p.a2 = (const bf16*)a2; p.gate = gate; p.w3 = (const bf16*)w3_bf16; p.z3 = (bf16*)z3;
+  p.a2 = (const f16*)a2; p.gate = gate; p.w3 = (const f16*)w3_f16; p.z3 = (f16*)z3;
   p.P = P; p.HW = HW; p.B = P / HW; p.mid = mid; p.cout = cout; p.dhw = make_fastdiv((unsigned)HW);
   if (v == 1) return launch_pw_project_fwd<256, 2, 6>(p, sums, (hipStream_t)stream, scratch, scratch_floats);
   if (v == 2) return launch_pw_project_fwd<64, 2, 6>(p, sums, (hipStream_t)stream, scratch, scratch_floats);
@@ -1026,7 +1049,7 @@ static int pw_project_fwd_impl(const void* a2, const float* xf_scale, const floa
 // row chunks by threads that each own one channel octet for the block's lifetime -- the same threads keep that octet's statistics
 // in registers, so no second pass and no atomics (slab + mmsim_launch_reduce at the end).
 struct PwExp {
-  const bf16* x; const bf16* w1; bf16* z1; float* parts;
+  const f16* x; const f16* w1; f16* z1; float* parts;      // w1: the fp16 weight shadow
   int P, mid, cin, nstrips, per_block;
 };
 
@@ -1075,29 +1098,29 @@ __global__ __launch_bounds__(256) void pw_expand_fwd_kernel(PwExp p) {
 #pragma unroll
     for (int m = 0; m < MT_W; ++m) {
       const int mt = wave * MT_W + m;
-      bf8 xf[KS];
+      h8 xf[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
-        xf[ks] = *reinterpret_cast<const bf8*>(ximg + (mt * 16 + (lane & 15)) * XP + (ks * 4 + (lane >> 4)) * 16);
+        xf[ks] = *reinterpret_cast<const h8*>(ximg + (mt * 16 + (lane & 15)) * XP + (ks * 4 + (lane >> 4)) * 16);
       for (int nt = 0; nt < NT; ++nt) {
         f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const bf8 wf = *reinterpret_cast<const bf8*>(wimg + (nt * 16 + (lane & 15)) * XP + (ks * 4 + (lane >> 4)) * 16);
-          acc = mfma16(wf, xf[ks], acc);                   // acc[e] = z1[pixel lane&15][channel nt*16 + 4(lane>>4) + e]
+          const h8 wf = *reinterpret_cast<const h8*>(wimg + (nt * 16 + (lane & 15)) * XP + (ks * 4 + (lane >> 4)) * 16);
+          acc = mfma16h(wf, xf[ks], acc);                  // acc[e] = z1[pixel lane&15][channel nt*16 + 4(lane>>4) + e]
         }
-        const bf4 o = {f2bf(acc[0]), f2bf(acc[1]), f2bf(acc[2]), f2bf(acc[3])};
-        *reinterpret_cast<bf4*>(oimg + (mt * 16 + (lane & 15)) * OP + (nt * 16 + (lane >> 4) * 4) * 2) = o;
+        const h4 o = {f2h(acc[0]), f2h(acc[1]), f2h(acc[2]), f2h(acc[3])};
+        *reinterpret_cast<h4*>(oimg + (mt * 16 + (lane & 15)) * OP + (nt * 16 + (lane >> 4) * 4) * 2) = o;
       }
     }
     __syncthreads();                     // C: the output image is complete
     if (owner) {
-      bf16* dst = p.z1 + (size_t)strip * BM * p.mid + un * 8;
+      f16* dst = p.z1 + (size_t)strip * BM * p.mid + un * 8;
       for (int pix = pl; pix < BM; pix += NR) {
         const uint4 v = *reinterpret_cast<const uint4*>(oimg + pix * OP + un * 16);
         *reinterpret_cast<uint4*>(dst + (size_t)pix * p.mid) = v;
         float f[8];
-        unpackN<8>(v, f);
+        unpack8h(v, f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { st[e] += f[e]; st[8 + e] += f[e] * f[e]; }
       }
@@ -1124,13 +1147,13 @@ extern "C" int mmsim_pw_expand_fwd_eligible(int P, int mid, int cin) {
   return P > 0 && (P % 64) == 0 && (mid % 8) == 0 && (cin % 8) == 0 && cin <= 32 && mid <= 192 && mid >= 64;
 }
 
-extern "C" int mmsim_pw_expand_fwd(const void* x, const void* w1_bf16, void* z1, float* sums, int P, int mid, int cin, float* scratch,
+extern "C" int mmsim_pw_expand_fwd(const void* x, const void* w1_f16, void* z1, float* sums, int P, int mid, int cin, float* scratch,
                                    unsigned long long scratch_floats, void* stream) {
-  MMSIM_REQUIRE(x && w1_bf16 && z1 && sums && scratch, "pw_expand_fwd: null operand");
+  MMSIM_REQUIRE(x && w1_f16 && z1 && sums && scratch, "pw_expand_fwd: null operand");
   MMSIM_REQUIRE(mmsim_pw_expand_fwd_eligible(P, mid, cin), "pw_expand_fwd: shape not eligible (see mmsim_pw_expand_fwd_eligible)");
   constexpr int BM = 64, CIN_T = 2;
   PwExp p;
-  p.x = (const bf16*)x; p.w1 = (const bf16*)w1_bf16; p.z1 = (bf16*)z1; p.P = P; p.mid = mid; p.cin = cin;
+  p.x = (const f16*)x; p.w1 = (const f16*)w1_f16; p.z1 = (f16*)z1; p.P = P; p.mid = mid; p.cin = cin;
   p.nstrips = P / BM;
   const int NT = (mid + 15) / 16, XP = CIN_T * 32 + 16, OP = NT * 32 + 16, G = mid / 8, NR = 256 / G;
   size_t lds = (size_t)BM * XP + (size_t)NT * 16 * XP + (size_t)BM * OP;
@@ -1155,7 +1178,7 @@ extern "C" int mmsim_pw_expand_fwd(const void* x, const void* w1_bf16, void* z1,
 // through an LDS output image so that it leaves as whole 16-byte row chunks; the weight gradient reads both operands with
 // transposing LDS reads and stays in registers for the block's lifetime (slab + mmsim_launch_reduce).
 struct PwPrjBwd {
-  const bf16* dz3; const bf16* a2; const float* gate; const bf16* w3; bf16* da; float* parts;
+  const bf16* dz3; const f16* a2; const float* gate; const bf16* w3; bf16* da; float* parts;      // w3: the bf16 weight shadow
   const float* xsc; const float* xsh;      // as in PwPrj
   int P, HW, B, mid, cout, nstrips, per_block, KS;
   FastDiv dhw;
@@ -1219,15 +1242,15 @@ __global__ __launch_bounds__(256) void pw_project_bwd_kernel(PwPrjBwd p) {
       if (q < nchunks) {
         const int pix = q / G, un = q - pix * G;
         const float* gr = grow + (pix >= split ? p.mid : 0) + un * 8;
-        const bf8 a = __builtin_bit_cast(bf8, va[i]);
+        const h8 a = __builtin_bit_cast(h8, va[i]);      // fp16 in HBM; staged as bf16: the weight-gradient MFMA pairs it with dz3 (bf16)
         bf8 o;
         if (p.xsc) {
           const float* cs = xs + un * 8;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = f2bf(silu_f(bf2f(a[e]) * cs[e] + cs[p.mid + e]) * gr[e]);
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(silu_f(h2f(a[e]) * cs[e] + cs[p.mid + e]) * gr[e]);
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(a[e]) * gr[e]);
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(h2f(a[e]) * gr[e]);
         }
         *reinterpret_cast<bf8*>(zimg + pix * ZP + un * 16) = o;
       }
@@ -1346,7 +1369,7 @@ static int pw_project_bwd_impl(const void* dz3, const void* a2, const float* xf_
   MMSIM_REQUIRE(v != 0, "pw_project_bwd: shape not eligible (see mmsim_pw_project_bwd_eligible)");
   PwPrjBwd p;
   p.xsc = xf_scale; p.xsh = xf_shift;
-  p.dz3 = (const bf16*)dz3; p.a2 = (const bf16*)a2; p.gate = gate; p.w3 = (const bf16*)w3_bf16; p.da = (bf16*)da;
+  p.dz3 = (const bf16*)dz3; p.a2 = (const f16*)a2; p.gate = gate; p.w3 = (const bf16*)w3_bf16; p.da = (bf16*)da;
   p.P = P; p.HW = HW; p.B = P / HW; p.mid = mid; p.cout = cout; p.dhw = make_fastdiv((unsigned)HW);
   if (v == 1) return launch_pw_project_bwd<128, 2, 3, 2, 2>(p, dw3, (hipStream_t)stream, scratch, scratch_floats);
   return launch_pw_project_bwd<64, 2, 6, 1, 6>(p, dw3, (hipStream_t)stream, scratch, scratch_floats);
@@ -1367,7 +1390,7 @@ extern "C" int mmsim_pw_expand_bwd(const void* dpre, const void* z1, const void*
                 "pw_expand_bwd: null operand");
   MMSIM_REQUIRE(mmsim_pw_expand_bwd_eligible(P, mid, cin), "pw_expand_bwd: shape not eligible (see mmsim_pw_expand_bwd_eligible)");
   PwBwd p;
-  p.dpre = (const bf16*)dpre; p.z1 = (const bf16*)z1; p.x = (const bf16*)x; p.resid = (const bf16*)resid; p.w1 = (const bf16*)w1_bf16;
+  p.dpre = (const bf16*)dpre; p.z1 = (const f16*)z1; p.x = (const f16*)x; p.resid = (const bf16*)resid; p.w1 = (const bf16*)w1_bf16;
   p.sc1 = scale1; p.mu1 = mean1; p.rs1 = rstd1; p.sums1 = sums1; p.dx = (bf16*)dx; p.dgamma = dgamma1; p.dbeta = dbeta1;
   p.P = P; p.mid = mid; p.cin = cin; p.invP = 1.0f / (float)P;
   if (cin <= 32 && mid <= 192) return launch_pw_expand_bwd<64, 2, 6>(p, dw1, (hipStream_t)stream, scratch, scratch_floats);

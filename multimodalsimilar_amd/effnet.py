@@ -1,11 +1,16 @@
 """MI355X-native EfficientNet image tower (the arithmetic of timm ``efficientnet_b0`` / ``efficientnet_b4`` that
 cv_classifier.py:23-27,49 calls; architecture per SURVEY.md Appendix C).
 
-Host-side schedule over the HIP kernels in csrc/conv.hip and csrc/gemm.hip.  Activations are NHWC bf16 so a 1x1
+Host-side schedule over the HIP kernels in csrc/conv.hip, csrc/mbconv.hip and csrc/gemm.hip.  Activations are NHWC so a 1x1
 conv is a GEMM over [pixels, channels]; every BatchNorm is train-mode (batch statistics); the BN+SiLU(+SE gate)
 that precedes the projection conv is applied while that GEMM stages its operand, so the widest tensors are
 written once and never re-materialised activated.  Parameter names / shapes are timm's, so state dicts
-interchange; all parameters live in one flat buffer (fp32 master, fp32 grad, bf16 shadow).
+interchange; all parameters live in one flat buffer (fp32 master, fp32 grad, bf16 + fp16 shadows).
+
+Element types: every FORWARD tensor (conv outputs, activations, block outputs) and the weight copy the forward products read
+are fp16 -- same bytes and MFMA rate as bf16, 11-bit significand: bf16 storage alone moved the embedding by 3.5-5 % against
+north_star's 1e-2, fp16 moves it by ~0.6 % (oracle/effnet_ref.py emulate="fp16"); every GRADIENT tensor and the weight copy
+the data-gradient products read are bf16 (per-element gradients of the 112x112 maps sit below fp16's normal range).
 """
 import math
 import os
@@ -133,7 +138,7 @@ class EfficientNet(nn.Module):
             conv(n + (".conv_pw" if b.type == "ds" else ".conv_pwl"), (b.cout, b.mid, 1, 1)); bn(n + "." + p_bn, b.cout)
         conv("conv_head", (a.head, a.last, 1, 1)); bn("bn2", a.head)
         self._bn_list = bns
-        self._flat = FlatBuffer(specs, device="cpu")
+        self._flat = FlatBuffer(specs, device="cpu", f16_shadow=True)
         self._init_weights(seed)
         for name, _ in specs:
             path, leaf = name.rsplit(".", 1)
@@ -319,9 +324,9 @@ class EfficientNet(nn.Module):
     def _block_fwd(self, st, b, cur, H, W):
         """One MBConv block: (expand 1x1 -> BN -> SiLU) -> depthwise -> BN -> SiLU -> SE -> project 1x1 -> BN (+skip)."""
         fl, s = self._flat, ops._stream()
-        B, dev, bf = st.B, cur.device, torch.bfloat16
+        B, dev, bf = st.B, cur.device, torch.float16          # forward tensors: fp16 (module docstring)
         E = lambda *sh, dt=bf: torch.empty(*sh, dtype=dt, device=dev)
-        V, SV = fl.view, fl.sview
+        V, SV = fl.view, fl.sview16                               # forward products read the fp16 weight shadow
         n = b.name
         e_bn, d_bn, p_bn = _bn_names(b)
         bs = SimpleNamespace(x_in=cur, H=H, W=W)
@@ -418,7 +423,7 @@ class EfficientNet(nn.Module):
         x = x.contiguous().float()
         B, _, Hi, Wi = x.shape
         dev = x.device
-        bf = torch.bfloat16
+        bf = torch.float16                                        # forward tensors: fp16
         self._step_seed += 1
         self._gen = getattr(self, "_gen", 0) + 1      # BN statistics live in module scratch (bnstat): see _run_backward
         st = SimpleNamespace(B=B, Hi=Hi, Wi=Wi, x=x, blocks=[], gen=self._gen)
@@ -427,7 +432,7 @@ class EfficientNet(nn.Module):
         st.sums_f = self._buf("sums_f", (2 * self._bn_total,), torch.float32)
         st.sums_f.zero_()
         E = lambda *sh, dt=bf: torch.empty(*sh, dtype=dt, device=dev)
-        V, SV = fl.view, fl.sview
+        V, SV = fl.view, fl.sview16
         # ---- stem
         H, W = Hi // 2, Wi // 2
         P = B * H * W

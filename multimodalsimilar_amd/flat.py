@@ -13,8 +13,12 @@ ALIGN = 8   # elements: every tensor starts 16-byte aligned in the bf16 shadow (
 
 
 class FlatBuffer:
-    def __init__(self, specs, device="cpu"):
-        """specs: ordered [(name, shape)].  Order is layout: neighbours are contiguous (q|k|v fusion)."""
+    def __init__(self, specs, device="cpu", f16_shadow=False):
+        """specs: ordered [(name, shape)].  Order is layout: neighbours are contiguous (q|k|v fusion).
+        f16_shadow: also keep an fp16 copy (``shadow16`` / ``sview16``) -- the image tower's forward products read fp16 weights
+        (fp16 activations, csrc/common.h), its data-gradient products the bf16 copy."""
+        self.f16_shadow = f16_shadow
+        self.shadow16 = None
         self.names = [n for n, _ in specs]
         self.shapes = {n: tuple(s) for n, s in specs}
         self.offsets = {}
@@ -49,6 +53,9 @@ class FlatBuffer:
     def sview(self, name, shape=None):
         return self._view(self.shadow, name, shape)
 
+    def sview16(self, name, shape=None):
+        return self._view(self.shadow16, name, shape)
+
     def span(self, first, last):
         """[start, end) element range covering tensors first..last (inclusive, in layout order)."""
         o = self.offsets[last]
@@ -62,6 +69,7 @@ class FlatBuffer:
         self.master = fn(self.master)
         self.grad = None
         self.shadow = None
+        self.shadow16 = None
         self._shadow_version = None
 
     def ensure_device_state(self):
@@ -70,6 +78,9 @@ class FlatBuffer:
         if self.shadow is None or self.shadow.device != self.master.device:
             self.shadow = torch.empty(self.total, dtype=torch.bfloat16, device=self.master.device)
             self._shadow_version = None
+        if self.f16_shadow and (self.shadow16 is None or self.shadow16.device != self.master.device):
+            self.shadow16 = torch.empty(self.total, dtype=torch.float16, device=self.master.device)
+            self._shadow_version = None
 
     def sync_shadow(self, force=False):
         """Refresh the bf16 copies if torch-side code modified the master (the AdamW kernel keeps them in sync itself)."""
@@ -77,6 +88,8 @@ class FlatBuffer:
         v = self.master._version
         if force or self._shadow_version != v:
             ops.cast_to_bf16(self.master, self.shadow)
+            if self.f16_shadow:
+                ops.cast_to_f16(self.master, self.shadow16)
             self._shadow_version = v
 
     def zero_grad(self, lazy=False):

@@ -11,6 +11,7 @@ import torch
 from ._lib import lib, MmsimError
 
 BF16 = torch.bfloat16
+F16 = torch.float16
 F32 = torch.float32
 I64 = torch.int64
 
@@ -128,10 +129,22 @@ def alloc_2d(rows, cols, dtype, device, mult=8, zero=False):
 
 def gemm(a, b, c, *, trans_a=False, b_kmajor=True, bias=None, epilogue=EPI_NONE, aux_in=None, aux_out=None,
          alpha=1.0, split_k=1, accumulate=False):
-    """c[M,N] = alpha * op(a) @ op(b) (+ bias) with fused epilogue; see mmsim_gemm_bf16."""
-    _chk(a, BF16, "gemm.a", 2); _chk(b, BF16, "gemm.b", 2)
-    if c.dtype not in (BF16, F32):
-        raise TypeError("gemm.c: bf16 or f32 output")
+    """c[M,N] = alpha * op(a) @ op(b) (+ bias) with fused epilogue; see mmsim_gemm_bf16.
+    The element format follows the operand dtypes (mmsim_gemm_fmt): bf16 x bf16 (fmt 0); fp16 x fp16 -> fp16 / f32, forward layout
+    (fmt 1: the image tower's forward products); bf16^T x fp16 -> f32 (fmt 2: its weight gradients, activation operand fp16)."""
+    if a.dtype == F16 and b.dtype == F16:
+        fmt, cdt = 1, F16
+    elif a.dtype == BF16 and b.dtype == F16:
+        fmt, cdt = 2, F32
+    else:
+        fmt, cdt = 0, BF16
+    _chk(a, F16 if fmt == 1 else BF16, "gemm.a", 2); _chk(b, BF16 if fmt == 0 else F16, "gemm.b", 2)
+    if c.dtype not in (cdt, F32):
+        raise TypeError(f"gemm.c: {cdt} or f32 output for these operand dtypes")
+    if fmt == 1 and (trans_a or not b_kmajor or split_k != 1):
+        raise ValueError("gemm: fp16 operands are supported in the forward layout only (a [M,K], b [N,K], no split-K)")
+    if fmt == 2 and (not trans_a or b_kmajor):
+        raise ValueError("gemm: a bf16 gradient with an fp16 activation is the weight-gradient layout only (a [K,M], b [K,N])")
     _chk(c, c.dtype, "gemm.c", 2)
     M, N = c.shape
     K = a.shape[0] if trans_a else a.shape[1]
@@ -151,6 +164,11 @@ def gemm(a, b, c, *, trans_a=False, b_kmajor=True, bias=None, epilogue=EPI_NONE,
             if tuple(t.shape) != (M, N):
                 raise ValueError(f"{nm}: shape must equal the output shape")
             ld_aux = _ld(t)
+    if fmt:
+        lib.gemm_fmt(fmt, int(trans_a), int(b_kmajor), M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(c), _ld(c),
+                     int(c.dtype == F32), _p(bias), epilogue, _p(aux_in), _p(aux_out), ld_aux, float(alpha), split_k,
+                     int(accumulate), _stream())
+        return c
     lib.gemm_bf16(int(trans_a), int(b_kmajor), M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(c), _ld(c),
                   int(c.dtype == F32), _p(bias), epilogue, _p(aux_in), _p(aux_out), ld_aux, float(alpha), split_k,
                   int(accumulate), _stream())
@@ -355,6 +373,13 @@ def cast_to_bf16(x, y):
     lib.cast_f32_to_bf16(_p(x), _p(y), x.numel(), _stream())
 
 
+def cast_to_f16(x, y):
+    _chk(x, F32, "cast.x"); _chk(y, F16, "cast.y")
+    if x.numel() != y.numel() or not x.is_contiguous() or not y.is_contiguous():
+        raise ValueError("cast: contiguous tensors of equal size")
+    lib.cast_f32_to_f16(_p(x), _p(y), x.numel(), _stream())
+
+
 def cast_to_f32(x, y):
     _chk(x, BF16, "cast.x"); _chk(y, F32, "cast.y")
     if x.numel() != y.numel() or not x.is_contiguous() or not y.is_contiguous():
@@ -362,15 +387,17 @@ def cast_to_f32(x, y):
     lib.cast_bf16_to_f32(_p(x), _p(y), x.numel(), _stream())
 
 
-def adamw_step(p, g, m, v, shadow, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, dev_hyper=None):
+def adamw_step(p, g, m, v, shadow, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, dev_hyper=None, shadow16=None):
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, F32, "adamw." + n, 1)
         if t.numel() != p.numel():
             raise ValueError("adamw: buffers must have equal length")
     if shadow is not None:
         _chk(shadow, BF16, "adamw.shadow", 1)
-    lib.adamw_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
-                   float(weight_decay), int(step), float(grad_scale), _p(dev_hyper), _stream())
+    if shadow16 is not None:
+        _chk(shadow16, F16, "adamw.shadow16", 1)
+    lib.adamw_step2(_p(p), _p(g), _p(m), _p(v), _p(shadow), _p(shadow16), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                    float(weight_decay), int(step), float(grad_scale), _p(dev_hyper), _stream())
 
 
 def adamw_rows_l2norm(p2d, g2d, m2d, v2d, w_hat, inv_norm, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, l2_eps=1e-12,

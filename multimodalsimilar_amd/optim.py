@@ -97,7 +97,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 rn.mark_normalised()
                 continue
             ops.adamw_step(f.master, f.grad, mv[0], mv[1], f.shadow, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                           g["weight_decay"], self._t, self.grad_scale, dev_hyper=self.dev_hyper)
+                           g["weight_decay"], self._t, self.grad_scale, dev_hyper=self.dev_hyper, shadow16=f.shadow16)
             f._shadow_version = f.master._version
             if rn is not None:
                 rn.invalidate_normalised()          # the master changed under the module: its cached w_hat is stale

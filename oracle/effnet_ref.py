@@ -153,8 +153,12 @@ def _se(x, sd, n):
 
 
 def _q(t, on):
-    """bf16 storage emulation (round to bf16, compute in fp32); gradient passes straight through the casts."""
-    return t.bfloat16().float() if on else t
+    """Storage emulation (round to the storage type, compute in fp32); the gradient passes straight through the casts.
+    on: False / None = off; True or "bf16" = bf16 (the rounds-1/2 layout of the MI355X path); "fp16" = IEEE half (the layout since
+    round 3: forward tensors of the image tower are stored as fp16)."""
+    if not on:
+        return t
+    return t.half().float() if on == "fp16" else t.bfloat16().float()
 
 
 def mbconv_forward(sd, n, b, x, training=True, stats=None, e=False):
@@ -179,15 +183,15 @@ def mbconv_forward(sd, n, b, x, training=True, stats=None, e=False):
     return _q(x, e)
 
 
-def backbone_forward(sd, model_name, x, training=True, stats=None, taps=None, emulate_bf16=False):
+def backbone_forward(sd, model_name, x, training=True, stats=None, taps=None, emulate_bf16=False, emulate=None):
     """x [B,3,H,W] -> feature map [B,head,H/32,W/32].  sd keys carry the 'backbone.' prefix.
 
-    emulate_bf16=True rounds to bf16 exactly where the MI355X path stores bf16 (conv outputs before BatchNorm,
-    activated tensors that are materialised, block outputs, 1x1-conv weights) and keeps fp32 everywhere else.
-    It is the same algorithm; it separates "bf16 storage" error from implementation error in the parity tests."""
+    emulate="fp16" / "bf16" (emulate_bf16=True == "bf16") rounds to that type exactly where the MI355X path stores 16-bit
+    tensors (conv outputs before BatchNorm, activated tensors that are materialised, block outputs, 1x1-conv weights) and keeps
+    fp32 everywhere else.  It is the same algorithm; it separates storage error from implementation error in the parity tests."""
     a = arch(model_name)
     p = "backbone."
-    e = emulate_bf16
+    e = emulate if emulate else emulate_bf16
     x = _q(_conv_k(x, sd[p + "conv_stem.weight"], 2, 3), e)
     x = _q(F.silu(_bn(x, sd, p + "bn1", training, stats)), e)
     if taps is not None:
@@ -201,12 +205,13 @@ def backbone_forward(sd, model_name, x, training=True, stats=None, taps=None, em
     return x
 
 
-def cv_predict_emb(sd, model_name, x, use_fc=True, training=True, stats=None, taps=None, emulate_bf16=False):
+def cv_predict_emb(sd, model_name, x, use_fc=True, training=True, stats=None, taps=None, emulate_bf16=False, emulate=None):
     """cv_classifier.py:47-55 (dropout = identity)."""
-    f = backbone_forward(sd, model_name, x, training, stats, taps, emulate_bf16)
+    em = emulate if emulate else emulate_bf16
+    f = backbone_forward(sd, model_name, x, training, stats, taps, emulate=em)
     e = f.mean((2, 3))                                    # AdaptiveAvgPool2d(1).view(B,-1)   :50
     if use_fc:
-        e = F.linear(_q(e, emulate_bf16), _q(sd["fc.weight"], emulate_bf16), sd["fc.bias"])   # :53
+        e = F.linear(_q(e, em), _q(sd["fc.weight"], em), sd["fc.bias"])   # :53
         e = _bn(e, sd, "bn", training, stats)             # :54
     return e
 

@@ -1,24 +1,23 @@
-"""Inference-path parity (SURVEY 8f-1; VERDICT r1 item 3): eval-mode image tower / two-tower embedding / cosine logits
+"""Inference-path parity (SURVEY 8f-1; VERDICT r1 item 3, r2 item 1): eval-mode image tower / two-tower embedding / cosine logits
 against the CPU oracle on WELL-CONDITIONED weights -- BatchNorm running statistics equal to the batch statistics of the data
 (what training leaves), small last-BatchNorm gamma in every residual block (what a trained residual network looks like) --
 where running-statistic BatchNorm does not amplify rounding differences the way ~100 train-mode BatchNorms at random init do.
 multimodal_classifier.py:44-57, cv_classifier.py:47-55, arcface.py:65-67.
 
-What the bound is and why.  north_star's bf16 tolerance is 1e-2; the TEXT half and the loss meet it here (0.5 % / 0.3 %).  The
-image embedding cannot, for a reason that is not the implementation: with activations STORED in bf16 the fp32 oracle itself,
-running the identical algorithm with only its stored tensors rounded (oracle/effnet_ref.py emulate_bf16), moves by d0 = 3.5-5 %
-on these (random-weight) EfficientNets even in eval mode -- ONE rounded tensor (the stem output alone, or the first depthwise
-output alone) already moves the embedding by ~0.8 %, i.e. a random-weight EfficientNet amplifies a 0.1 % rms perturbation ~7x, and
-~12 kinds of stored tensor add in quadrature (measured per rounding site on the CPU).  So the test pins the
-HIP path to that self-measured storage floor: error <= 1.35 d0 + 0.5 %, printed next to d0 (measured: 4.5-5.9 % against d0 =
-4.5-4.8 %).  Anything an implementation adds on top of bf16 storage -- a wrong tap, a missed BatchNorm term, a stale statistic --
-shows as a multiple of d0, as the per-block teacher-forced tests (2-4 %) show it per block."""
+The bound is north_star's: embeddings within 1e-2 (relative L2) for 16-bit storage.  Rounds 1-2 stored the image tower's
+activations as bf16 and measured 4.5-5.9 % here (the fp32 oracle itself moves by 4.4-4.7 % when only its stored tensors are
+rounded to bf16); since round 3 the forward tensors are fp16 (same bytes, 11-bit significand; csrc/common.h): the oracle under
+fp16-storage emulation moves by d0 = 0.55-0.67 %, and the assertions below are the plain `e < 1e-2` again.  d0 is printed and
+logged beside every measurement (tests/parity_log.py -> profiles/parity_r03.json)."""
 import warnings
 
 import pytest
 import torch
 
+from parity_log import check, record
+
 pytestmark = pytest.mark.gpu
+NORTH_STAR = 1e-2      # BASELINE.json north_star: outputs within 1e-2 for 16-bit storage
 DEV = "cuda"
 
 
@@ -69,7 +68,7 @@ def test_image_tower_eval_mode_matches_the_oracle(name, use_fc, res):
     g = torch.Generator().manual_seed(9)
     xe = torch.randn(10, 3, res, res, generator=g)                     # fresh data through the running statistics
     ref = effnet_ref.cv_predict_emb(sd, name, xe, use_fc=use_fc, training=False)
-    emu = effnet_ref.cv_predict_emb(sd, name, xe, use_fc=use_fc, training=False, emulate_bf16=True)
+    emu = effnet_ref.cv_predict_emb(sd, name, xe, use_fc=use_fc, training=False, emulate="fp16")
     model.to(DEV).eval()
     with torch.no_grad():
         emb = model.predict_emb(xe.to(DEV))
@@ -78,11 +77,12 @@ def test_image_tower_eval_mode_matches_the_oracle(name, use_fc, res):
     e, d0 = l2err(emb, ref), l2err(emu, ref)
     cos_ref = arcface_ref.arcface_forward_test(ref, sd["classifier.weight"])
     ce = (cos.cpu() - cos_ref).abs().max().item()
-    print(f"\n[{name} eval, fc={use_fc}, {res}^2] embedding L2 err {e:.4f} (oracle under bf16-storage emulation: {d0:.4f}); max |dcos| {ce:.4f}")
+    print(f"\n[{name} eval, fc={use_fc}, {res}^2] embedding L2 err {e:.4f} (oracle under fp16-storage emulation: {d0:.4f}); max |dcos| {ce:.4f}")
     assert torch.equal(emb, emb2)                                      # eval: deterministic
-    assert e < 1.35 * d0 + 0.005 and e < 0.08, (e, d0)                 # at the bf16-storage floor of the oracle itself (see header)
-    cos_emu = arcface_ref.arcface_forward_test(emu, sd["classifier.weight"])
-    assert ce < 1.35 * (cos_emu - cos_ref).abs().max().item() + 0.005, (ce, (cos_emu - cos_ref).abs().max().item())
+    tag = f"image_tower_eval_mode[{name}-fc{int(use_fc)}-{res}]"
+    record(tag, "oracle under fp16-storage emulation: embedding relative L2 (d0)", d0, NORTH_STAR)
+    check(tag, "embedding relative L2", e, NORTH_STAR)                  # north_star: 1e-2 for 16-bit storage
+    check(tag, "max |cos - cos_ref| (cosine logits, unit scale)", ce, NORTH_STAR)
     # running statistics untouched by an eval forward
     assert torch.equal(model.backbone.bn1.running_mean.cpu(), sd["backbone.bn1.running_mean"])
     assert int(model.backbone.bn1.num_batches_tracked) == int(sd["backbone.bn1.num_batches_tracked"])
@@ -90,15 +90,15 @@ def test_image_tower_eval_mode_matches_the_oracle(name, use_fc, res):
 
 @pytest.mark.parametrize("name,use_fc,res", [("efficientnet_b0", True, 64), ("efficientnet_b4", False, 64)])
 def test_image_tower_train_mode_on_conditioned_weights(name, use_fc, res):
-    """Train-mode (batch-statistic BatchNorm) whole-tower forward + backward on the conditioned weights: loss within 1e-2,
-    embedding within 3 %, gradients within the oracle's own bf16-emulation envelope."""
+    """Train-mode (batch-statistic BatchNorm) whole-tower forward + backward on the conditioned weights: embedding and loss within
+    north_star's 1e-2; parameter gradients (bf16 gradient tensors through the whole tower) reported and bounded at 3 % median / 4 % p90 (measured 1.6-1.9 % / 2.1-2.3 %)."""
     from oracle import effnet_ref, arcface_ref
     model, sd, x = conditioned_cv(name, use_fc, seed=5, res=res, batch=16)
     y = torch.randint(0, 50, (16,), generator=torch.Generator().manual_seed(6))
     res_ = {}
     for emu in (False, True):
         sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
-        emb_ref = effnet_ref.cv_predict_emb(sdr, name, x, use_fc=use_fc, training=True, emulate_bf16=emu)
+        emb_ref = effnet_ref.cv_predict_emb(sdr, name, x, use_fc=use_fc, training=True, emulate="fp16" if emu else None)
         loss_ref = arcface_ref.ce_loss(arcface_ref.arcface_forward(emb_ref, sdr["classifier.weight"], y, 64.0, 0.2), y)
         loss_ref.backward()
         res_[emu] = (emb_ref.detach(), loss_ref.item(), {k: v.grad for k, v in sdr.items() if torch.is_tensor(v) and v.grad is not None})
@@ -123,11 +123,14 @@ def test_image_tower_train_mode_on_conditioned_weights(name, use_fc, res):
     print(f"\n[{name} train, conditioned] emb L2 err {e:.4f} (emulation {d0:.4f}); loss {loss.item():.4f} vs {loss_ref:.4f} "
           f"(emulation {loss_emu:.4f}); grad L2 median {ge[len(ge) // 2]:.3f} / p90 {ge[int(0.9 * len(ge))]:.3f} "
           f"(emulation {g0[len(g0) // 2]:.3f} / {g0[int(0.9 * len(g0))]:.3f}) over {len(keys)} tensors")
-    assert e < 1.35 * d0 + 0.005 and e < 0.08, (e, d0)
-    assert abs(loss.item() - loss_ref) < 1e-2 * loss_ref                                  # north_star's 1e-2 on what the step optimises
-    # gradients: the same floor rule as the embedding (factor 1.35 of what bf16 storage alone does to the oracle) + 2 % absolute; over
-    # different atomic orderings of the default mode the median moved between 0.097 and 0.12 on B0, hence the deterministic run above
-    assert ge[len(ge) // 2] < 1.35 * g0[len(g0) // 2] + 0.02 and ge[int(0.9 * len(ge))] < 1.35 * g0[int(0.9 * len(g0))] + 0.02
+    tag = f"image_tower_train_mode_conditioned[{name}]"
+    record(tag, "oracle under fp16-storage emulation: embedding relative L2 (d0)", d0, NORTH_STAR)
+    check(tag, "embedding relative L2", e, NORTH_STAR)
+    check(tag, "loss relative error", abs(loss.item() - loss_ref) / loss_ref, NORTH_STAR)          # what the step optimises
+    # gradients: bf16 gradient tensors through ~50-100 layers (the forward is fp16, the backward keeps bf16's range); over different
+    # atomic orderings of the default mode the median moved by +-0.01 on B0, hence the deterministic run above
+    check(tag, "median parameter-gradient relative L2", ge[len(ge) // 2], 3e-2)
+    check(tag, "p90 parameter-gradient relative L2", ge[int(0.9 * len(ge))], 4e-2)
 
 
 def test_two_tower_eval_embedding_and_forward_test_match_the_oracle():
@@ -159,17 +162,19 @@ def test_two_tower_eval_embedding_and_forward_test_match_the_oracle():
     ref = arcface_ref.glue_concat(e_img, e_txt)
     cos_ref = arcface_ref.arcface_forward_test(ref, model.classifier.weight.detach().cpu())
     e = l2err(emb, ref)
-    e_img_emu = effnet_ref.cv_predict_emb(sd_cv, "efficientnet_b0", img, use_fc=False, training=False, emulate_bf16=True)
+    e_img_emu = effnet_ref.cv_predict_emb(sd_cv, "efficientnet_b0", img, use_fc=False, training=False, emulate="fp16")
     d0 = l2err(torch.nn.functional.normalize(e_img_emu), torch.nn.functional.normalize(e_img))
     ei, et = l2err(emb[:, :1280], ref[:, :1280]), l2err(emb[:, 1280:], ref[:, 1280:])
-    print(f"\n[two-tower eval] embedding L2 err {e:.4f}; halves: image {ei:.4f} (bf16-storage floor of the oracle {d0:.4f}), text {et:.4f}")
-    assert et < 1e-2                                                   # text half: north_star's 1e-2
-    assert ei < 1.35 * d0 + 0.005                                      # image half: the oracle's own bf16-storage floor (see header)
-    cos_emu = arcface_ref.arcface_forward_test(arcface_ref.glue_concat(e_img_emu, e_txt), model.classifier.weight.detach().cpu())
-    assert (cos.cpu() - cos_ref).abs().max() < 1.35 * (cos_emu - cos_ref).abs().max() + 0.005
+    print(f"\n[two-tower eval] embedding L2 err {e:.4f}; halves: image {ei:.4f} (oracle under fp16-storage emulation {d0:.4f}), text {et:.4f}")
+    tag = "two_tower_eval_embedding"
+    record(tag, "oracle under fp16-storage emulation: image half relative L2 (d0)", d0, NORTH_STAR)
+    check(tag, "text half relative L2", et, NORTH_STAR)                 # north_star: 1e-2 (bf16 text tower)
+    check(tag, "image half relative L2", ei, NORTH_STAR)                # north_star: 1e-2 (fp16 image tower)
+    check(tag, "whole embedding relative L2", e, NORTH_STAR)
+    err = (cos.cpu() - cos_ref).abs().max()
+    check(tag, "max |cos - cos_ref| (forward_test logits, unit scale)", err, NORTH_STAR)
     # predictions: wherever the reference's top-1 margin exceeds twice the measured cosine error the argmax must agree (random-weight
     # classes are near-tied: a fixed agreement rate over ten rows is a coin flip on the ties, not a property of the kernels)
-    err = (cos.cpu() - cos_ref).abs().max()
     top2 = cos_ref.topk(2, dim=1).values
     clear = (top2[:, 0] - top2[:, 1]) > 2 * err
     assert (cos.argmax(1).cpu()[clear] == cos_ref.argmax(1)[clear]).all()

@@ -1,9 +1,13 @@
 """Image-tower parity on the MI355X: conv kernels against fp32 torch references of the same op, and the whole
 EfficientNet / CvClassifier forward + backward against the CPU oracle (oracle/effnet_ref.py; PARITY UNPINNED
-w.r.t. timm, see its header).  bf16 activations: 1e-2-class tolerances, looser on deep-chain gradients."""
+w.r.t. timm, see its header).  Element types (include/mmsim_hip.h, EfficientNet section): FORWARD tensors fp16 (`nhwc`, `.half()`),
+GRADIENT tensors bf16 (`nhwc_g`, `.bfloat16()`): fp16-class tolerances on forward outputs (2e-3 of the output scale), 1e-2-class on
+bf16 gradients, looser on deep-chain gradients."""
 import pytest
 import torch
 import torch.nn.functional as F
+
+from parity_log import check, record
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -34,9 +38,17 @@ def scr():
     return _SCR["t"].data_ptr(), _SCR["t"].numel()
 
 
-def nhwc(x):      # [B,C,H,W] fp32 -> [B*H*W, C] bf16
+def nhwc(x):      # [B,C,H,W] fp32 -> [B*H*W, C] fp16: a FORWARD tensor of the image tower
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous().half()
+
+
+def nhwc_g(x):    # the same as bf16: a GRADIENT tensor
     B, C, H, W = x.shape
     return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous().bfloat16()
+
+
+FWD_TOL = 2e-3    # fp16 outputs: half an ulp is 2.4e-4 of the value; max-norm relative bound with margin for the accumulation order
 
 
 def nchw(x, B, H, W):
@@ -56,14 +68,14 @@ def test_depthwise_conv_fwd_bwd(K, S, H, C):
     Ho, Wo = ref.shape[2], ref.shape[3]
     wT = torch.empty(K * K, C, device=DEV)
     lib.dw_weight_to_tap_major(w.data_ptr(), wT.data_ptr(), C, K, s)
-    z = torch.empty(B * Ho * Wo, C, dtype=torch.bfloat16, device=DEV)
+    z = torch.empty(B * Ho * Wo, C, dtype=torch.float16, device=DEV)
     sums = torch.zeros(2 * C, device=DEV)
     lib.dwconv_fwd(a.data_ptr(), wT.data_ptr(), z.data_ptr(), sums.data_ptr(), B, H, W, C, K, S, *scr(), s)
-    assert relerr(nchw(z, B, Ho, Wo), ref) < 1e-2
+    assert relerr(nchw(z, B, Ho, Wo), ref) < FWD_TOL
     zf = z.float()
     assert relerr(sums[:C], zf.sum(0)) < 1e-3 and relerr(sums[C:], (zf * zf).sum(0)) < 1e-3
     dz = rnd(B, C, Ho, Wo, seed=3)
-    dzb = nhwc(dz)
+    dzb = nhwc_g(dz)
     ref.backward(nchw(dzb, B, Ho, Wo))
     # plain transposed conv (+ residual)
     res = rnd(B * H * W, C, seed=4).bfloat16()
@@ -72,7 +84,7 @@ def test_depthwise_conv_fwd_bwd(K, S, H, C):
                         B, H, W, C, K, S, *scr(), s)
     assert relerr(nchw(dx, B, H, W), xr.grad + nchw(res, B, H, W)) < 1e-2
     # fused with the producer's BN + SiLU backward
-    z1 = rnd(B * H * W, C, seed=5).bfloat16()
+    z1 = rnd(B * H * W, C, seed=5).half()
     mean, rstd = rnd(C, seed=6, scale=0.1), 1 + 0.1 * rnd(C, seed=7).abs()
     scale, shift = 1 + 0.1 * rnd(C, seed=8), 0.1 * rnd(C, seed=9)
     bsum = torch.zeros(2 * C, device=DEV)
@@ -92,7 +104,7 @@ def test_depthwise_conv_fwd_bwd(K, S, H, C):
     lib.dw_grad_from_tap_major(gT.data_ptr(), g.data_ptr(), C, K, s)
     assert relerr(g - 1, wr.grad) < 1e-2
     # the same gradient with the operand re-formed from the pre-BatchNorm tensor (stride-2 blocks store no a1): a = silu(sc z + sh)
-    a_from = (F.silu(z1.float() * scale + shift)).bfloat16()
+    a_from = (F.silu(z1.float() * scale + shift)).half()
     gT_a = torch.zeros(K * K, C, device=DEV)
     lib.dwconv_bwd_weight(dzb.data_ptr(), a_from.data_ptr(), gT_a.data_ptr(), B, H, W, C, K, S, *scr(), s)
     gT_x = torch.zeros(K * K, C, device=DEV)
@@ -111,16 +123,16 @@ def test_tiled_depthwise_forward(K, S, H, C, xf):
     z1 = nhwc(rnd(B, C, H, W, seed=1))
     scale, shift = 1 + 0.1 * rnd(C, seed=8), 0.1 * rnd(C, seed=9)
     w = rnd(C, 1, K, K, seed=2, scale=0.3)
-    a = F.silu(z1.float() * scale + shift).bfloat16() if xf else z1
+    a = F.silu(z1.float() * scale + shift).half() if xf else z1
     ref = F.conv2d(nchw(a, B, H, W), w, None, stride=S, padding=K // 2, groups=C)
     Ho, Wo = ref.shape[2], ref.shape[3]
     wT = torch.empty(K * K, C, device=DEV)
     lib.dw_weight_to_tap_major(w.data_ptr(), wT.data_ptr(), C, K, s)
-    z = torch.full((B * Ho * Wo, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    z = torch.full((B * Ho * Wo, C), float("nan"), dtype=torch.float16, device=DEV)
     sums = torch.zeros(2 * C, device=DEV)
     lib.dwtile_fwd(z1.data_ptr(), scale.data_ptr() if xf else None, shift.data_ptr() if xf else None, wT.data_ptr(), z.data_ptr(),
                    sums.data_ptr(), B, H, W, C, K, S, *scr(), s)
-    assert relerr(nchw(z, B, Ho, Wo), ref) < 1e-2
+    assert relerr(nchw(z, B, Ho, Wo), ref) < FWD_TOL
     zf = z.float()
     assert relerr(sums[:C], zf.sum(0)) < 1e-3 and relerr(sums[C:], (zf * zf).sum(0)) < 1e-3
 
@@ -135,9 +147,9 @@ def test_tiled_depthwise_backward_equals_the_unfused_kernels(K, H, C, plain, res
     lib, s = _lib()
     B, W = 3, H + 1
     P, HW = B * H * W, H * W
-    z2 = rnd(P, C, seed=1, scale=1.5).bfloat16()
+    z2 = rnd(P, C, seed=1, scale=1.5).half()
     dy = rnd(P, C, seed=2).bfloat16()
-    z1 = rnd(P, C, seed=3, scale=1.5).bfloat16()
+    z1 = rnd(P, C, seed=3, scale=1.5).half()
     w = rnd(C, 1, K, K, seed=4, scale=0.3)
     gate, dsq = torch.sigmoid(rnd(B, C, seed=5)), rnd(B, C, seed=6)
     mk = lambda sd: (rnd(C, seed=sd, scale=0.1), 1 + 0.1 * rnd(C, seed=sd + 1).abs(), 1 + 0.1 * rnd(C, seed=sd + 2), 0.1 * rnd(C, seed=sd + 3))
@@ -152,7 +164,7 @@ def test_tiled_depthwise_backward_equals_the_unfused_kernels(K, H, C, plain, res
     dg_ref, db_ref = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     lib.bn_bwd(dy.data_ptr(), z2.data_ptr(), mu2.data_ptr(), rs2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), gate.data_ptr(),
                dsq.data_ptr(), HW, 1, sums2.data_ptr(), 0, dz2.data_ptr(), dg_ref.data_ptr(), db_ref.data_ptr(), P, C, *scr(), s)
-    a1 = z1 if plain else F.silu(z1.float() * sc1 + sh1).bfloat16()
+    a1 = z1 if plain else F.silu(z1.float() * sc1 + sh1).half()
     gT_ref = torch.zeros(K * K, C, device=DEV)
     lib.dwconv_bwd_weight(dz2.data_ptr(), a1.data_ptr(), gT_ref.data_ptr(), B, H, W, C, K, 1, *scr(), s)
     out_ref = torch.empty(P, C, dtype=torch.bfloat16, device=DEV)
@@ -188,8 +200,8 @@ def test_fused_expand_backward_equals_bn_backward_plus_two_products(P, mid, cin,
     lib, s = _lib()
     assert lib.pw_expand_bwd_eligible(P, mid, cin) == 1
     dpre = rnd(P, mid, seed=1).bfloat16()
-    z1 = rnd(P, mid, seed=2, scale=1.5).bfloat16()
-    x = rnd(P, cin, seed=3).bfloat16()
+    z1 = rnd(P, mid, seed=2, scale=1.5).half()
+    x = rnd(P, cin, seed=3).half()
     res = rnd(P, cin, seed=4).bfloat16() if skip else None
     w1 = rnd(mid, cin, seed=5, scale=0.2).bfloat16()
     mean, rstd, scale = rnd(mid, seed=6, scale=0.1), 1 + 0.1 * rnd(mid, seed=7).abs(), 1 + 0.1 * rnd(mid, seed=8)
@@ -216,7 +228,7 @@ def test_fused_expand_backward_equals_bn_backward_plus_two_products(P, mid, cin,
     assert relerr(dx, dx_ref) < 1e-2
     assert relerr(gw - 0.5, gw_ref - 0.5) < 5e-3
     assert relerr(dg, dg_ref) < 1e-5 and relerr(db, db_ref) < 1e-5
-    # and against fp32 autograd of the same formulae (both paths round dz1 to bf16)
+    # and against fp32 autograd of the same formulae (both paths round dz1 to bf16; the weight gradient also rounds x to bf16)
     dz = scale * (df - sums[:mid] / P - zh * sums[mid:] / P)
     assert relerr(dx, dz @ w1.float() + (res.float() if skip else 0)) < 1.5e-2
     assert relerr(gw - 0.5, dz.t() @ x.float()) < 1e-2
@@ -227,7 +239,7 @@ def test_batchnorm_stats_apply_backward(C, P):
     lib, s = _lib()
     HW = 7 if P % 7 == 0 else 1
     B = P // HW
-    z = rnd(P, C, seed=1, scale=2.0).bfloat16()
+    z = rnd(P, C, seed=1, scale=2.0).half()
     gamma, beta = 1 + 0.2 * rnd(C, seed=2), 0.2 * rnd(C, seed=3)
     sums = torch.zeros(2 * C, device=DEV)
     lib.bn_stats(z.data_ptr(), sums.data_ptr(), P, C, *scr(), s)
@@ -240,11 +252,11 @@ def test_batchnorm_stats_apply_backward(C, P):
     rm2, rv2 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     yr = F.batch_norm(zr, rm2, rv2, g_, b_, True, 0.1, 1e-5)
     assert torch.allclose(rm, rm2, atol=1e-4) and torch.allclose(rv, rv2, rtol=1e-3, atol=1e-4)
-    res = rnd(P, C, seed=4).bfloat16()
+    res = rnd(P, C, seed=4).half()                  # the skip connection: a forward tensor
     out = torch.empty_like(z)
     lib.bn_apply(z.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.data_ptr(), out.data_ptr(), P, C, 1, s)
     act = F.silu(yr)
-    assert relerr(out, act + res.float()) < 1e-2
+    assert relerr(out, act + res.float()) < FWD_TOL
     # pooled mean of the activated output, and backward with SiLU + SE gate terms
     pooled = torch.empty(B, C, device=DEV)
     lib.pool_bn_act(z.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, pooled.data_ptr(), B, HW, C, 1, 1.0 / HW, s)
@@ -256,7 +268,7 @@ def test_batchnorm_stats_apply_backward(C, P):
     total = ((act.view(B, HW, C) * gate.unsqueeze(1)).reshape(P, C) * dy.float()).sum() + (sq * extra).sum()
     total.backward()
     bs = torch.zeros(2 * C, device=DEV)
-    dz = torch.empty_like(z)
+    dz = torch.empty(P, C, dtype=torch.bfloat16, device=DEV)
     dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     lib.bn_bwd(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                gate.data_ptr(), extra.data_ptr(), HW, 1, bs.data_ptr(), 0, dz.data_ptr(), dg.data_ptr(), db.data_ptr(), P, C, *scr(), s)
@@ -299,27 +311,27 @@ def test_stem_conv_and_transformed_pointwise_gemm():
     xr, wr = x.clone(), w.clone().requires_grad_(True)
     ref = F.conv2d(xr, wr, None, stride=2, padding=1)
     Ho, Wo = ref.shape[2:]
-    z = torch.empty(B * Ho * Wo, Co, dtype=torch.bfloat16, device=DEV)
+    z = torch.empty(B * Ho * Wo, Co, dtype=torch.float16, device=DEV)
     sums = torch.zeros(2 * Co, device=DEV)
     lib.stem_fwd(x.data_ptr(), w.data_ptr(), z.data_ptr(), sums.data_ptr(), B, H, W, Co, *scr(), s)
-    assert relerr(nchw(z, B, Ho, Wo), ref) < 1e-2
+    assert relerr(nchw(z, B, Ho, Wo), ref) < FWD_TOL
     assert relerr(sums[:Co], z.float().sum(0)) < 1e-3
-    dz = nhwc(rnd(B, Co, Ho, Wo, seed=3))
+    dz = nhwc_g(rnd(B, Co, Ho, Wo, seed=3))
     ref.backward(nchw(dz, B, Ho, Wo))
     dw = torch.zeros_like(w)
     lib.stem_wgrad(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Co, *scr(), s)
     assert relerr(dw, wr.grad) < 2e-3
     # 1x1 conv on silu(scale*z+shift)*gate, forward and weight gradient
     P, Cin, Cout, HW = 360, 144, 40, 30
-    z2 = rnd(P, Cin, seed=4).bfloat16()
+    z2 = rnd(P, Cin, seed=4).half()
     scale, shift = 1 + 0.1 * rnd(Cin, seed=5), 0.1 * rnd(Cin, seed=6)
     gate = torch.sigmoid(rnd(P // HW, Cin, seed=7))
-    w3 = rnd(Cout, Cin, seed=8, scale=0.2).bfloat16()
+    w3 = rnd(Cout, Cin, seed=8, scale=0.2).half()
     a = (F.silu(z2.float() * scale + shift).view(P // HW, HW, Cin) * gate.unsqueeze(1)).reshape(P, Cin)
-    out = torch.empty(P, Cout, dtype=torch.bfloat16, device=DEV)
+    out = torch.empty(P, Cout, dtype=torch.float16, device=DEV)
     lib.gemm_bf16_xf(1, P, Cout, Cin, z2.data_ptr(), Cin, w3.data_ptr(), Cin, out.data_ptr(), Cout, 0, scale.data_ptr(),
                      shift.data_ptr(), gate.data_ptr(), HW, 1, 0, s)
-    assert relerr(out, a @ w3.float().t()) < 1.5e-2
+    assert relerr(out, a @ w3.float().t()) < FWD_TOL
     dz3 = rnd(P, Cout, seed=9).bfloat16()
     gw = torch.zeros(Cout, Cin, device=DEV)
     lib.gemm_bf16_xf(2, Cout, Cin, P, dz3.data_ptr(), Cout, z2.data_ptr(), Cin, gw.data_ptr(), Cin, 1, scale.data_ptr(),
@@ -369,7 +381,7 @@ def test_mbconv_block_teacher_forced(name, idx):
     xr = nchw(xb, B, H, H).cpu().requires_grad_(True)
     ref = effnet_ref.mbconv_forward(sdr, prefix, ob, xr, training=True)
     Ho = ref.shape[2]
-    dout = nhwc(torch.randn(B, b.cout, Ho, Ho, generator=g).to(DEV))
+    dout = nhwc_g(torch.randn(B, b.cout, Ho, Ho, generator=g).to(DEV))
     ref.backward(nchw(dout, B, Ho, Ho).cpu())
     # HIP block
     model._flat.sync_shadow()
@@ -381,19 +393,24 @@ def test_mbconv_block_teacher_forced(name, idx):
     st.sums_b = model._buf("sums_b", (2 * model._bn_total,), torch.float32); st.sums_b.zero_()
     out, Ho2, Wo2 = model._block_fwd(st, b, xb, H, H)
     assert Ho2 == Ho
-    assert relerr(nchw(out, B, Ho, Ho), ref) < 2e-2, "block output"
+    tag = f"mbconv_block_teacher_forced[{name}-{idx}]"
+    # forward: fp16 storage of z1 / z2 / (a2) / z3 / the output -- a tenth of north_star's 1e-2 (measured 4-7e-4; bf16 storage: 2-4e-2)
+    check(tag, "block output, max-norm relative", relerr(nchw(out, B, Ho, Ho), ref), 2e-3)
+    check(tag, "block output, relative L2", l2err(nchw(out, B, Ho, Ho), ref), 1e-3)
     dx = model._block_bwd(st, b, st.blocks[-1], dout)
-    assert l2err(nchw(dx, B, H, H), xr.grad) < 3e-2, "input gradient"
+    check(tag, "input gradient, relative L2 (bf16 gradients)", l2err(nchw(dx, B, H, H), xr.grad), 1e-2)
     named = dict(model.named_parameters())
     gmax = max(sdr[k].grad.norm().item() for k in keys)
-    checked = 0
+    checked, worst = 0, 0.0
     for k in keys:
         gref = sdr[k].grad
         if gref.norm().item() < 1e-5 * gmax:
             continue      # analytically-zero gradient (a constant in front of a BatchNorm)
         e = l2err(named[k[len("backbone."):]].grad, gref)
-        assert e < 4e-2, (k, e)
+        worst = max(worst, e)
+        assert e < 2e-2, (k, e)
         checked += 1
+    record(tag, "worst parameter gradient, relative L2 (bf16 gradients)", worst, 2e-2)
     assert checked >= 8
 
 
@@ -422,7 +439,7 @@ def test_cv_classifier_matches_oracle(name, use_fc):
     res = {}
     for emu in (False, True):
         sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
-        emb_ref = effnet_ref.cv_predict_emb(sdr, name, x, use_fc=use_fc, training=True, emulate_bf16=emu)
+        emb_ref = effnet_ref.cv_predict_emb(sdr, name, x, use_fc=use_fc, training=True, emulate="fp16" if emu else None)
         loss_ref = arcface_ref.ce_loss(arcface_ref.arcface_forward(emb_ref, sdr["classifier.weight"], y, 64.0, 0.2), y)
         loss_ref.backward()
         res[emu] = (emb_ref.detach(), loss_ref.item(), {k: v.grad for k, v in sdr.items() if torch.is_tensor(v) and v.grad is not None})
@@ -438,16 +455,18 @@ def test_cv_classifier_matches_oracle(name, use_fc):
     g0 = sorted(l2err(grads_emu[k], grads[k]) for k in keys)
     ge = sorted(l2err(named[k].grad, grads[k]) for k in keys)
     e = l2err(emb, emb_ref)
-    print(f"\n[{name}] emb L2 err {e:.4f} (bf16-emulation envelope d0 {d0:.4f}); loss {loss.item():.4f} vs {loss_ref:.4f}; "
+    print(f"\n[{name}] emb L2 err {e:.4f} (fp16-storage emulation of the oracle d0 {d0:.4f}); loss {loss.item():.4f} vs {loss_ref:.4f}; "
           f"grad L2 median {ge[len(ge) // 2]:.3f} (envelope {g0[len(g0) // 2]:.3f}) over {len(keys)} tensors")
     assert len(keys) > 50
     # RANDOM-INIT smoke (ill-conditioned on purpose: ~50-100 train-mode BatchNorms at init amplify every rounding).  The tight
-    # whole-tower checks are in tests/test_gpu_eval_parity.py (conditioned weights, eval and train mode); here the HIP path must
-    # stay inside the envelope the oracle itself spans when only its STORED tensors are rounded to bf16 (factor 1.35, as there),
-    # and the loss within 1e-2 plus the oracle's own loss displacement under that emulation (factor 1).
-    assert e < 1.35 * d0 + 0.01
-    assert abs(loss.item() - loss_ref) < 1e-2 * loss_ref + abs(loss_emu - loss_ref)
-    assert ge[len(ge) // 2] < 1.35 * g0[len(g0) // 2] + 0.02
+    # whole-tower checks are in tests/test_gpu_eval_parity.py (conditioned weights, eval and train mode: 1e-2).  Here: the embedding
+    # within twice what fp16 STORAGE alone does to the oracle (+1 %), the loss within north_star's 1e-2, the median parameter
+    # gradient (bf16 gradient tensors through ~100 layers) within 8 %.
+    tag = f"cv_classifier_matches_oracle[{name}]"
+    record(tag, "oracle under fp16-storage emulation: embedding relative L2 (d0)", d0, 1.0)
+    check(tag, "embedding relative L2 (random init, train mode)", e, 2.0 * d0 + 0.01)
+    check(tag, "loss relative error", abs(loss.item() - loss_ref) / loss_ref, 1e-2)
+    check(tag, "median parameter-gradient relative L2", ge[len(ge) // 2], 8e-2)
     # running statistics follow torch semantics (momentum 0.1, unbiased variance); two forward passes were run
     stats = {}
     effnet_ref.cv_predict_emb(sd, name, x, use_fc=use_fc, training=True, stats=stats)
@@ -463,15 +482,15 @@ def test_cv_classifier_matches_oracle(name, use_fc):
 @pytest.mark.parametrize("P,Cin,Cout,xf", [(1000, 24, 144, 0), (6272, 96, 40, 1), (513, 48, 24, 0), (12544, 272, 448, 1)])
 def test_pointwise_conv_with_bn_statistics(P, Cin, Cout, xf):
     """conv_pw / conv_pwl + the statistics pass of the following BatchNorm2d in one launch: output equals the plain GEMM,
-    sums equal sum / sum of squares of the bf16-rounded output (ragged M, N tiles included)."""
+    sums equal sum / sum of squares of the fp16-rounded output (ragged M, N tiles included)."""
     torch.manual_seed(P + Cin)
     hw = 49
     B = (P + hw - 1) // hw
-    x = torch.randn(P, Cin, device=DEV).bfloat16()
-    w = (torch.randn(Cout, Cin, device=DEV) * 0.2).bfloat16()
+    x = torch.randn(P, Cin, device=DEV).half()
+    w = (torch.randn(Cout, Cin, device=DEV) * 0.2).half()
     sc, sh = torch.rand(Cin, device=DEV) + 0.5, torch.randn(Cin, device=DEV) * 0.3
     gate = torch.rand(B, Cin, device=DEV)
-    z = torch.empty(P, Cout, dtype=torch.bfloat16, device=DEV)
+    z = torch.empty(P, Cout, dtype=torch.float16, device=DEV)
     sums = torch.zeros(2 * Cout, device=DEV)
     lib, s = _lib()
     lib.gemm_bf16_bnstats(xf, P, Cout, Cin, x.data_ptr(), Cin, w.data_ptr(), Cin, z.data_ptr(), Cout,
@@ -480,9 +499,9 @@ def test_pointwise_conv_with_bn_statistics(P, Cin, Cout, xf):
     a = x.float()
     if xf:
         a = torch.nn.functional.silu(a * sc + sh) * gate.repeat_interleave(hw, 0)[:P]
-        a = a.bfloat16().float()
+        a = a.half().float()
     ref = a @ w.float().t()
-    assert relerr(z, ref) < 1e-2
+    assert relerr(z, ref) < FWD_TOL
     zf = z.float()
     ssum, ssq = zf.double().sum(0), (zf.double() ** 2).sum(0)
     assert (sums[:Cout].double() - ssum).abs().max() < 1e-4 * zf.abs().double().sum(0).max() + 1e-3      # fp32 summation order
@@ -495,24 +514,24 @@ def test_squeeze_that_keeps_the_activation_and_gate_only_operand():
     lib, s = _lib()
     B, HW, Cin, Cout = 6, 49, 144, 40
     P = B * HW
-    z2 = rnd(P, Cin, seed=4).bfloat16()
+    z2 = rnd(P, Cin, seed=4).half()
     scale, shift = 1 + 0.1 * rnd(Cin, seed=5), 0.1 * rnd(Cin, seed=6)
     a_ref = F.silu(z2.float() * scale + shift)
-    a2 = torch.empty(P, Cin, dtype=torch.bfloat16, device=DEV)
+    a2 = torch.empty(P, Cin, dtype=torch.float16, device=DEV)
     sq = torch.empty(B, Cin, device=DEV)
     lib.pool_bn_act_store(z2.data_ptr(), scale.data_ptr(), shift.data_ptr(), a2.data_ptr(), sq.data_ptr(), B, HW, Cin, 1.0 / HW, s)
-    assert relerr(a2, a_ref) < 1e-2
+    assert relerr(a2, a_ref) < FWD_TOL
     assert relerr(sq, a_ref.view(B, HW, Cin).mean(1)) < 1e-3
     sq2 = torch.empty(B, Cin, device=DEV)
     lib.pool_bn_act(z2.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, sq2.data_ptr(), B, HW, Cin, 1, 1.0 / HW, s)
     assert torch.equal(sq, sq2)                      # the pooled value does not depend on whether a2 is kept
     gate = torch.sigmoid(rnd(B, Cin, seed=7))
-    w3 = rnd(Cout, Cin, seed=8, scale=0.2).bfloat16()
+    w3 = rnd(Cout, Cin, seed=8, scale=0.2).half()
     ag = (a2.float().view(B, HW, Cin) * gate.unsqueeze(1)).reshape(P, Cin)
-    out = torch.empty(P, Cout, dtype=torch.bfloat16, device=DEV)
+    out = torch.empty(P, Cout, dtype=torch.float16, device=DEV)
     lib.gemm_bf16_xf(1, P, Cout, Cin, a2.data_ptr(), Cin, w3.data_ptr(), Cin, out.data_ptr(), Cout, 0, None, None, gate.data_ptr(),
                      HW, 1, 0, s)
-    assert relerr(out, ag @ w3.float().t()) < 1.5e-2
+    assert relerr(out, ag @ w3.float().t()) < FWD_TOL
     dz3 = rnd(P, Cout, seed=9).bfloat16()
     gw = torch.zeros(Cout, Cin, device=DEV)
     lib.gemm_bf16_xf(2, Cout, Cin, P, dz3.data_ptr(), Cout, a2.data_ptr(), Cin, gw.data_ptr(), Cin, 1, None, None, gate.data_ptr(),
@@ -530,7 +549,7 @@ def test_paired_backward_products_equal_the_separate_launches(P, Cin, Cout, HW, 
     from multimodalsimilar_amd import ops
     lib, s = _lib()
     dy = rnd(P, Cout, seed=1).bfloat16()
-    xin = rnd(P, Cin, seed=2).bfloat16()
+    xin = rnd(P, Cin, seed=2).half()                # the activation operand of the weight gradient: fp16
     gate = torch.sigmoid(rnd(P // HW, Cin, seed=3))
     w = rnd(Cout, Cin, seed=4, scale=0.2).bfloat16()
     res = torch.randn(P, Cin, device=DEV).bfloat16()
@@ -577,21 +596,21 @@ def test_streaming_projection_forward_equals_the_gemm_form(B, HW, mid, cout):
     lib, s = _lib()
     P = B * HW
     assert lib.pw_project_fwd_eligible(P, HW, mid, cout)
-    a2 = rnd(P, mid, seed=1).bfloat16()
+    a2 = rnd(P, mid, seed=1).half()
     gate = torch.sigmoid(rnd(B, mid, seed=2))
-    w3 = rnd(cout, mid, seed=3, scale=0.2).bfloat16()
-    z3 = torch.empty(P, cout, dtype=torch.bfloat16, device=DEV)
+    w3 = rnd(cout, mid, seed=3, scale=0.2).half()
+    z3 = torch.empty(P, cout, dtype=torch.float16, device=DEV)
     sums = torch.zeros(2 * cout, device=DEV)
     lib.pw_project_fwd(a2.data_ptr(), gate.data_ptr(), w3.data_ptr(), z3.data_ptr(), sums.data_ptr(), P, HW, mid, cout, *scr(), s)
-    a = ((a2.float().view(B, HW, mid) * gate.unsqueeze(1)).bfloat16().float()).reshape(P, mid)      # the operand as staged (bf16)
+    a = ((a2.float().view(B, HW, mid) * gate.unsqueeze(1)).half().float()).reshape(P, mid)      # the operand as staged (fp16)
     ref = a @ w3.float().t()
-    assert relerr(z3, ref) < 1e-2
+    assert relerr(z3, ref) < FWD_TOL
     assert relerr(sums[:cout], z3.float().sum(0)) < 1e-4 and relerr(sums[cout:], (z3.float() ** 2).sum(0)) < 1e-4
     z3g = torch.empty_like(z3)
     sums_g = torch.zeros_like(sums)
     lib.gemm_bf16_bnstats(1, P, cout, mid, a2.data_ptr(), mid, w3.data_ptr(), mid, z3g.data_ptr(), cout, None, None, gate.data_ptr(), HW,
                           sums_g.data_ptr(), *scr(), s)
-    assert relerr(z3, z3g) < 4e-3 and relerr(sums, sums_g) < 2e-3
+    assert relerr(z3, z3g) < 1e-3 and relerr(sums, sums_g) < 2e-3
     assert not lib.pw_project_fwd_eligible(P, HW, 1632, 272) and not lib.pw_project_fwd_eligible(P, HW, mid, cout + 4)
 
 
@@ -604,9 +623,9 @@ def test_streaming_projection_backward_equals_the_gemm_form(B, HW, mid, cout):
     lib, s = _lib()
     P = B * HW
     assert lib.pw_project_bwd_eligible(P, HW, mid, cout)
-    a2 = rnd(P, mid, seed=1).bfloat16()
+    a2 = rnd(P, mid, seed=1).half()
     gate = torch.sigmoid(rnd(B, mid, seed=2))
-    w3 = rnd(cout, mid, seed=3, scale=0.2).bfloat16()
+    w3 = rnd(cout, mid, seed=3, scale=0.2).bfloat16()      # the data gradient reads the bf16 weight shadow
     dz3 = rnd(P, cout, seed=4).bfloat16()
     base = rnd(cout, mid, seed=5)
     da = torch.empty(P, mid, dtype=torch.bfloat16, device=DEV)
@@ -629,18 +648,18 @@ def test_streaming_expansion_forward_equals_the_gemm_form(P, mid, cin):
     the threads that copy it out) against fp32 torch and mmsim_gemm_bf16_bnstats."""
     lib, s = _lib()
     assert lib.pw_expand_fwd_eligible(P, mid, cin)
-    x = rnd(P, cin, seed=1).bfloat16()
-    w1 = rnd(mid, cin, seed=2, scale=0.3).bfloat16()
-    z1 = torch.empty(P, mid, dtype=torch.bfloat16, device=DEV)
+    x = rnd(P, cin, seed=1).half()
+    w1 = rnd(mid, cin, seed=2, scale=0.3).half()
+    z1 = torch.empty(P, mid, dtype=torch.float16, device=DEV)
     sums = torch.zeros(2 * mid, device=DEV)
     lib.pw_expand_fwd(x.data_ptr(), w1.data_ptr(), z1.data_ptr(), sums.data_ptr(), P, mid, cin, *scr(), s)
-    assert relerr(z1, x.float() @ w1.float().t()) < 1e-2
+    assert relerr(z1, x.float() @ w1.float().t()) < FWD_TOL
     assert relerr(sums[:mid], z1.float().sum(0)) < 1e-4 and relerr(sums[mid:], (z1.float() ** 2).sum(0)) < 1e-4
     z1g = torch.empty_like(z1)
     sums_g = torch.zeros_like(sums)
     lib.gemm_bf16_bnstats(0, P, mid, cin, x.data_ptr(), cin, w1.data_ptr(), cin, z1g.data_ptr(), mid, None, None, None, 1,
                           sums_g.data_ptr(), *scr(), s)
-    assert torch.equal(z1, z1g) or relerr(z1, z1g) < 4e-3                 # one 32-deep MFMA step either way: usually bit-equal
+    assert torch.equal(z1, z1g) or relerr(z1, z1g) < 1e-3                 # one 32-deep MFMA step either way: usually bit-equal
     assert relerr(sums, sums_g) < 1e-3
     assert not lib.pw_expand_fwd_eligible(P, 336, 56) and not lib.pw_expand_fwd_eligible(P + 8, mid, cin)
 
@@ -651,27 +670,72 @@ def test_streaming_projection_with_the_activation_formed_on_the_fly(B, HW, mid, 
     stored).  Against fp32 torch and against the stored-a2 kernels fed with a2 = bf16(silu(scale z2 + shift))."""
     lib, s = _lib()
     P = B * HW
-    z2 = rnd(P, mid, seed=1).bfloat16()
+    z2 = rnd(P, mid, seed=1).half()
     scale, shift = 1 + 0.1 * rnd(mid, seed=6), 0.1 * rnd(mid, seed=7)
     gate = torch.sigmoid(rnd(B, mid, seed=2))
-    w3 = rnd(cout, mid, seed=3, scale=0.2).bfloat16()
+    w3 = rnd(cout, mid, seed=3, scale=0.2).half()
+    w3b = w3.float().bfloat16()                            # what the bf16 shadow of the same weights holds (backward)
     act = F.silu(z2.float() * scale + shift)
     ag = (act.view(B, HW, mid) * gate.unsqueeze(1)).reshape(P, mid)
-    z3 = torch.empty(P, cout, dtype=torch.bfloat16, device=DEV)
+    z3 = torch.empty(P, cout, dtype=torch.float16, device=DEV)
     sums = torch.zeros(2 * cout, device=DEV)
     lib.pw_project_fwd_xf(z2.data_ptr(), scale.data_ptr(), shift.data_ptr(), gate.data_ptr(), w3.data_ptr(), z3.data_ptr(),
                           sums.data_ptr(), P, HW, mid, cout, *scr(), s)
-    assert relerr(z3, ag @ w3.float().t()) < 1e-2
+    assert relerr(z3, ag @ w3.float().t()) < FWD_TOL
     assert relerr(sums[:cout], z3.float().sum(0)) < 1e-4
-    a2 = act.bfloat16()
+    a2 = act.half()
     z3s = torch.empty_like(z3)
     sums_s = torch.zeros_like(sums)
     lib.pw_project_fwd(a2.data_ptr(), gate.data_ptr(), w3.data_ptr(), z3s.data_ptr(), sums_s.data_ptr(), P, HW, mid, cout, *scr(), s)
-    assert relerr(z3, z3s) < 6e-3                      # one rounding (fp32 activation x gate) instead of two
+    assert relerr(z3, z3s) < 1e-3                      # one rounding (fp32 activation x gate) instead of two
     dz3 = rnd(P, cout, seed=4).bfloat16()
     da = torch.empty(P, mid, dtype=torch.bfloat16, device=DEV)
     dw = torch.zeros(cout, mid, device=DEV)
-    lib.pw_project_bwd_xf(dz3.data_ptr(), z2.data_ptr(), scale.data_ptr(), shift.data_ptr(), gate.data_ptr(), w3.data_ptr(),
+    lib.pw_project_bwd_xf(dz3.data_ptr(), z2.data_ptr(), scale.data_ptr(), shift.data_ptr(), gate.data_ptr(), w3b.data_ptr(),
                           da.data_ptr(), dw.data_ptr(), P, HW, mid, cout, *scr(), s)
-    assert relerr(da, dz3.float() @ w3.float()) < 1e-2
+    assert relerr(da, dz3.float() @ w3b.float()) < 1e-2
     assert relerr(dw, dz3.float().t() @ ag) < 5e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 72, 200), (256, 512, 1792), (1000, 40, 24)])
+def test_fp16_forward_product_and_mixed_weight_gradient(M, N, K):
+    """mmsim_gemm_fmt: fmt 1 (fp16 x fp16 -> fp16 / f32 + bias: the forward 1x1 convs and the fc layer of cv_classifier.py:53) and
+    fmt 2 (bf16 gradient^T x fp16 activation -> f32: their weight gradients) against fp32 torch; wrong layouts are refused."""
+    from multimodalsimilar_amd import ops
+    from multimodalsimilar_amd._lib import MmsimError
+    a = rnd(M, K, seed=1).half()
+    b = rnd(N, K, seed=2, scale=0.2).half()
+    ref = a.float() @ b.float().t()
+    c16 = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+    ops.gemm(a, b, c16)
+    assert relerr(c16, ref) < FWD_TOL
+    bias = rnd(N, seed=3)
+    c32 = torch.empty(M, N, device=DEV)
+    ops.gemm(a, b, c32, bias=bias)
+    assert relerr(c32, ref + bias) < 2e-4                       # fp32 accumulation of exact fp16 products
+    dy = rnd(M, N, seed=4).bfloat16()
+    gw = torch.full((N, K), 0.25, device=DEV)
+    ops.gemm(dy, a, gw, trans_a=True, b_kmajor=False, split_k=2, accumulate=True)
+    assert relerr(gw - 0.25, dy.float().t() @ a.float().bfloat16().float()) < 2e-3      # the activation enters the MFMA as bf16
+    with pytest.raises(ValueError):
+        ops.gemm(a, b, c16, b_kmajor=False)                     # fp16 operands: forward layout only
+    with pytest.raises(TypeError):
+        ops.gemm(a, b, torch.empty(M, N, dtype=torch.bfloat16, device=DEV))
+    lib, s = _lib()
+    with pytest.raises(MmsimError):                             # the C ABI refuses it too
+        lib.gemm_fmt(1, 1, 0, M, N, K, a.data_ptr(), K, b.data_ptr(), K, c32.data_ptr(), N, 1, None, 0, None, None, 0, 1.0, 1, 0, s)
+
+
+def test_adamw_writes_both_weight_shadows():
+    """mmsim_adamw_step2: the bf16 and the fp16 copies of the updated parameters (image tower: forward reads fp16, dgrad bf16)."""
+    from multimodalsimilar_amd import ops
+    n = 4096 + 8
+    p, g = rnd(n, seed=1), rnd(n, seed=2, scale=0.1)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    sb, sh = torch.empty(n, dtype=torch.bfloat16, device=DEV), torch.empty(n, dtype=torch.float16, device=DEV)
+    ops.adamw_step(p, g, m, v, sb, 1e-2, 0.9, 0.999, 1e-8, 0.01, 1, shadow16=sh)
+    assert torch.equal(sb, p.bfloat16()) and torch.equal(sh, p.half())
+    big = torch.full((8,), 1e6, device=DEV)
+    out = torch.empty(8, dtype=torch.float16, device=DEV)
+    ops.cast_to_f16(big, out)
+    assert torch.isfinite(out).all() and float(out[0]) == 65504.0      # saturating, never inf
