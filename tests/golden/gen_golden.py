@@ -5,9 +5,13 @@ It imports /root/reference's ``arcface`` and ``nlp_classifier`` (over HF ``BertM
 local config object - no downloads) and the exact optimiser/scheduler objects the reference's
 train script constructs, feeds them seeded synthetic inputs and stores inputs + outputs as .npz.
 Only the numeric vectors are committed; no reference source travels.
-cv_classifier / multimodal_classifier cannot be imported here (ModuleNotFoundError: timm), so
-the two-tower glue fixture composes the reference's ArcMarginProduct(m=0.5) with the three
-glue operations of multimodal_classifier.py:54-56 applied to stand-in tower embeddings.
+cv_classifier / multimodal_classifier cannot be imported as they are (ModuleNotFoundError: timm; torchvision is absent too).
+glue_0.npz composes the reference's ArcMarginProduct(m=0.5) with the three glue operations of multimodal_classifier.py:54-56
+applied to stand-in tower embeddings; multimodal_forward.npz (round 3) EXECUTES multimodal_classifier.py
+itself -- its __init__ (torch.load of two pickled towers), forward, forward(is_test=True) and predict_emb, lines 14-57 -- with
+empty stub modules named timm / torchvision placed in sys.modules INSIDE THIS GENERATOR ONLY (the reference imports them at
+module level and never uses them in that file), a small stand-in image tower exposing predict_emb, and the reference's own
+NlpClassifier over a tiny HF BertModel as the text tower.
 """
 import os
 import sys
@@ -63,13 +67,19 @@ def gen_arcface():
     npz("arcface_update_m.npz", deltas=np.array([0.04] * 25 + [-2.0, 0.5]), traj=np.array(traj))
 
 
-def gen_nlp():
+def gen_nlp(only_cfg=None):
     cfgs = {
         "tiny": dict(vocab_size=128, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
                      intermediate_size=512, max_position_embeddings=64, B=4, S=32, C=40, store_weights=True),
         "mid": dict(vocab_size=256, hidden_size=256, num_hidden_layers=2, num_attention_heads=4,
                     intermediate_size=1024, max_position_embeddings=128, B=2, S=128, C=300, store_weights=False),
+        # BASELINE config 1's shape (roberta-base: H 768, 12 heads, FFN 3072, vocab 21128, S 64, B 8, 1000 classes), ONE layer
+        # (the state is re-seeded on the test side, only vectors and gradient norms are stored)
+        "base1": dict(vocab_size=21128, hidden_size=768, num_hidden_layers=1, num_attention_heads=12,
+                      intermediate_size=3072, max_position_embeddings=512, B=8, S=64, C=1000, store_weights=False),
     }
+    if only_cfg is not None:
+        cfgs = {only_cfg: cfgs[only_cfg]}
     sys.path.insert(0, os.path.abspath(os.path.join(OUT, "..", "..")))
     from oracle import bert_ref
     for name, c in cfgs.items():
@@ -97,7 +107,10 @@ def gen_nlp():
         model = ref_nlp.NlpClassifier(ptm, num_labels=c["C"])
         model.train()   # dropout p=0 in config; NlpClassifier's own nn.Dropout is never applied (E6)
         with torch.no_grad():
-            model.classifier.weight.copy_(torch.randn(c["C"], c["hidden_size"], generator=g) * 0.05)
+            if name == "base1":      # re-seedable on the test side (the 3 MB head is not stored): its own generator
+                model.classifier.weight.copy_(torch.randn(c["C"], c["hidden_size"], generator=torch.Generator().manual_seed(13)) * 0.05)
+            else:
+                model.classifier.weight.copy_(torch.randn(c["C"], c["hidden_size"], generator=g) * 0.05)
         B, S = c["B"], c["S"]
         ids = torch.randint(0, c["vocab_size"], (B, S), generator=g)
         tt = torch.randint(0, 2, (B, S), generator=g)
@@ -124,7 +137,20 @@ def gen_nlp():
                 out["gnorm::" + k] = v.norm()
             out["g::pooler.dense.weight"] = grads["pooler.dense.weight"]
             out["g::encoder.layer.0.attention.self.query.bias"] = grads["encoder.layer.0.attention.self.query.bias"]
+            if name == "base1":      # a few full gradients, the 768 x 768 ones as float16 (relative 5e-4: far below the bounds they serve)
+                del out["g::pooler.dense.weight"], out["head_weight"]
+                out["seed_head"] = 13
+                out["head_grad"] = out["head_grad"].detach().numpy().astype(np.float16)
+                for k in ("encoder.layer.0.attention.self.value.weight", "encoder.layer.0.attention.output.dense.weight"):
+                    out["g::" + k] = grads[k].numpy().astype(np.float16)
+                for k in ("encoder.layer.0.intermediate.dense.bias", "encoder.layer.0.output.LayerNorm.weight"):
+                    out["g::" + k] = grads[k]
+                out["g64::embeddings.position_embeddings.weight"] = grads["embeddings.position_embeddings.weight"][:64]   # rows >= S are zero
         npz(f"nlp_{name}.npz", **out)
+
+
+def gen_nlp_base1():
+    gen_nlp("base1")
 
 
 def gen_glue():
@@ -143,6 +169,91 @@ def gen_glue():
     loss.backward()
     npz("glue_0.npz", img=img, txt=txt, weight=head.weight, label=label, final=final, logits=logits, loss=loss,
         dimg=img.grad, dtxt=txt.grad, dw=head.weight.grad)
+
+
+class StandInImageTower(torch.nn.Module):
+    """Stand-in for the pickled CvClassifier of multimodal_classifier.py:16 (timm is absent): anything with predict_emb.
+    Global average pool of the image -> Linear(3, 48) -> tanh x 3.  Its arithmetic is restated on the test side from the stored
+    weights; only the reference's OWN lines (14-57) are what the fixture pins."""
+
+    def __init__(self):
+        super().__init__()
+        self.fc = torch.nn.Linear(3, 48)
+
+    def predict_emb(self, img):
+        return 3.0 * torch.tanh(self.fc(img.mean((2, 3))))
+
+
+def gen_multimodal_forward():
+    """multimodal_classifier.py:14-57 executed as is (stub timm / torchvision modules only satisfy its imports)."""
+    import tempfile
+    import types
+    for name in ("timm", "timm.data", "timm.data.transforms_factory", "torchvision", "torchvision.transforms"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["timm.data"].resolve_data_config = None                      # names the reference imports and never calls here
+    sys.modules["timm.data.transforms_factory"].create_transform = None
+    sys.modules["timm"].data = sys.modules["timm.data"]
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    import multimodal_classifier as ref_mm
+    sys.path.insert(0, os.path.abspath(os.path.join(OUT, "..", "..")))
+    from oracle import bert_ref
+    c = dict(vocab_size=128, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
+             max_position_embeddings=64)
+    torch.manual_seed(7)
+    conf = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **c)
+    conf._attn_implementation = "eager"
+    ptm = BertModel(conf)
+    shape = bert_ref.BertShape(**c)
+    sd0 = bert_ref.init_state(shape, seed=11)                                # = the text tower of nlp_tiny.npz (same seeds)
+    g = torch.Generator().manual_seed(12)
+    for k in sd0:
+        if k.endswith("LayerNorm.weight"):
+            sd0[k] = 1.0 + 0.1 * torch.randn(sd0[k].shape, generator=g)
+        elif k.endswith(".bias"):
+            sd0[k] = 0.05 * torch.randn(sd0[k].shape, generator=g)
+    ptm.load_state_dict(sd0, strict=False)
+    nlp = ref_nlp.NlpClassifier(ptm, num_labels=5)                           # its own head is unused by the two-tower model
+    g = torch.Generator().manual_seed(31)
+    cv = StandInImageTower()
+    with torch.no_grad():
+        cv.fc.weight.copy_(torch.randn(48, 3, generator=g))
+        cv.fc.bias.copy_(0.1 * torch.randn(48, generator=g))
+    B, S, C, D = 6, 32, 30, 48 + 128
+    with tempfile.TemporaryDirectory() as td:
+        pc, pn = os.path.join(td, "cv.pt"), os.path.join(td, "nlp.pt")
+        torch.save(cv, pc)
+        torch.save(nlp, pn)
+        real_load = torch.load
+        torch.load = lambda f, *a, **k: real_load(f, *a, **{**k, "weights_only": False})     # whole-module pickles (SURVEY E10)
+        try:
+            model = ref_mm.MultimodalClassifier("cpu", pc, pn, emb_size=D, num_labels=C)       # :14-25
+        finally:
+            torch.load = real_load
+    model.train()
+    assert abs(model.classifier.m - 0.5) < 1e-12 and model.classifier.s == 64.0
+    with torch.no_grad():
+        model.classifier.weight.copy_(torch.randn(C, D, generator=g) * 0.1)
+    img = torch.randn(B, 3, 8, 8, generator=g)
+    ids = torch.randint(0, c["vocab_size"], (B, S), generator=g)
+    tt = torch.randint(0, 2, (B, S), generator=g)
+    lens = torch.randint(S // 4, S + 1, (B,), generator=g)
+    lens[0] = S
+    mask = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).long()
+    label = torch.randint(0, C, (B,), generator=g)
+    final = model.predict_emb(img, ids, tt, None, mask)                                         # :44-57
+    logits = model(img, ids, tt, None, mask, label)                                             # :27-40
+    loss = torch.nn.CrossEntropyLoss()(logits, label)
+    loss.backward()
+    logits_test = model(img, ids, tt, None, mask, label, is_test=True)                          # :41-42
+    grads = {n: p.grad for n, p in model.nlp.ptm.named_parameters() if p.grad is not None}
+    # model.cv is the unpickled COPY of `cv` (multimodal_classifier.py:16): its gradients live there
+    npz("multimodal_forward.npz", img=img, input_ids=ids, token_type_ids=tt, attention_mask=mask, label=label,
+        cv_fc_weight=cv.fc.weight, cv_fc_bias=cv.fc.bias, head_weight=model.classifier.weight, final=final, logits=logits,
+        logits_test=logits_test, loss=loss, head_grad=model.classifier.weight.grad, cv_fc_weight_grad=model.cv.fc.weight.grad,
+        cv_fc_bias_grad=model.cv.fc.bias.grad, **{"g::pooler.dense.weight": grads["pooler.dense.weight"],
+                                            "g::encoder.layer.1.output.dense.weight": grads["encoder.layer.1.output.dense.weight"]},
+        seed_state=11, seed_perturb=12)
 
 
 def gen_optim():
@@ -260,6 +371,6 @@ def gen_preprocess():
 
 if __name__ == "__main__":
     only = sys.argv[1] if len(sys.argv) > 1 else None
-    for fn in (gen_arcface, gen_nlp, gen_glue, gen_optim, gen_multilabel, gen_preprocess):
+    for fn in (gen_arcface, gen_nlp, gen_glue, gen_optim, gen_multilabel, gen_preprocess, gen_nlp_base1, gen_multimodal_forward):
         if only is None or fn.__name__ == "gen_" + only:
             fn()

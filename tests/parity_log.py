@@ -12,7 +12,8 @@ PATH = os.environ.get("MMSIM_PARITY_LOG") or os.path.join(ROOT, "gpurun_out", "p
 
 
 def record(test, metric, measured, bound, ok=None):
-    measured, bound = float(measured), float(bound)
+    measured = float(measured.detach()) if hasattr(measured, "detach") else float(measured)
+    bound = float(bound)
     ok = bool(measured < bound) if ok is None else bool(ok)
     try:
         os.makedirs(os.path.dirname(PATH), exist_ok=True)

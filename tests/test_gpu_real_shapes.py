@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+from parity_log import check, record      # noqa: E402
 
 
 def l2err(a, b):
@@ -61,17 +62,27 @@ def test_bert_large_layer_at_cfg3_shape_matches_the_oracle():
     ref_logits = arcface_ref.arcface_forward(pooled, hw, y, 64.0, 0.40)
     ref_loss = arcface_ref.ce_loss(ref_logits, y)
     ref_loss.backward()
-    assert abs(loss.item() - ref_loss.item()) < 1e-2 * ref_loss.item(), (loss.item(), ref_loss.item())
+    tag = "bert_large_layer_cfg3_shape"
+    check(tag, "loss relative error", abs(loss.item() - ref_loss.item()) / ref_loss.item(), 1e-2)
     with torch.no_grad():
         emb = model.predict_emb(ids.to(DEV), None, None, mask.to(DEV))
-    assert l2err(emb, pooled) < 1e-2
-    # near-ties may flip under bf16 (10 000 random classes: the top two logits of a row are often within the bf16 rounding of the
-    # cosines); measured 0.965-0.98 depending on which GEMM kernel accumulates the cosines and on the oracle's own summation order
-    assert (am.cpu() == ref_logits.argmax(1)).float().mean() > 0.95
+        logits = model(ids.to(DEV), None, None, mask.to(DEV), y.to(DEV))          # the literal path: materialised margin logits
+    check(tag, "pooled embedding relative L2", l2err(emb, pooled), 1e-2)
+    err = (logits.cpu() - ref_logits.detach()).abs().max().item()
+    check(tag, "max |logit - oracle| / 64", err / 64.0, 1e-2)
+    # predictions: 10 000 random classes leave the top two logits of many rows closer than the measured logit error -- on those
+    # rows the argmax is a coin flip for ANY 16-bit path, not a property of the kernels.  Wherever the oracle's top-1 margin
+    # exceeds twice the measured error the prediction must agree, for every such row; the raw agreement rate is recorded.
+    top2 = ref_logits.detach().topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2 * err
+    record(tag, "argmax agreement over all 256 rows (near-ties included)", (am.cpu() == ref_logits.argmax(1)).float().mean(), 2.0)
+    record(tag, "rows whose oracle top-1 margin exceeds twice the logit error", clear.float().mean(), 2.0)
+    assert clear.float().mean() > 0.5
+    assert (am.cpu()[clear] == ref_logits.argmax(1)[clear]).all()
     named = dict(model.ptm.named_parameters())
-    for k in keys:
-        assert l2err(named[k].grad, sdr[k].grad) < 5e-2, (k, l2err(named[k].grad, sdr[k].grad))
-    assert l2err(model.classifier.weight.grad, hw.grad) < 3e-2
+    worst = max(l2err(named[k].grad, sdr[k].grad) for k in keys)
+    check(tag, "worst parameter gradient relative L2 (11 tensors)", worst, 5e-2)
+    check(tag, "head gradient relative L2", l2err(model.classifier.weight.grad, hw.grad), 3e-2)
 
 
 def test_head_at_cfg4_shape_matches_the_oracle():
@@ -97,14 +108,16 @@ def test_head_at_cfg4_shape_matches_the_oracle():
     loss, am = head.forward_loss(xd, y.to(DEV))
     loss.backward()
     head.check_labels()
-    assert abs(loss.item() - ref.item()) < 2e-3 * ref.item(), (loss.item(), ref.item())
+    tag = "head_cfg4_shape"
+    check(tag, "loss relative error", abs(loss.item() - ref.item()) / ref.item(), 2e-3)
+    record(tag, "argmax agreement over 256 rows", (am.cpu() == logits.argmax(1)).float().mean(), 2.0)
     assert (am.cpu() == logits.argmax(1)).float().mean() > 0.98
-    assert l2err(xd.grad, xr.grad) < 2e-2
+    check(tag, "dx relative L2", l2err(xd.grad, xr.grad), 2e-2)
     rows = torch.cat([y[:32], torch.randint(0, C, (64,), generator=g)])
     assert l2err(head.weight.grad.cpu()[rows], W.grad[rows]) < 2e-2
-    assert l2err(head.weight.grad, W.grad) < 2e-2
+    check(tag, "dW relative L2", l2err(head.weight.grad, W.grad), 2e-2)
     cos = head.forward_test(xd.detach())
-    assert (cos.cpu() - arcface_ref.arcface_forward_test(x, W.detach())).abs().max() < 6e-3
+    check(tag, "max |forward_test cosine - oracle|", (cos.cpu() - arcface_ref.arcface_forward_test(x, W.detach())).abs().max(), 6e-3)
     # the literal API path at this shape: materialised margin logits
     lg = head(xd.detach(), y.to(DEV))
     assert (lg.cpu() - logits.detach()).abs().max() < 0.4          # 64-scale: 6e-3 on the cosines

@@ -6,7 +6,11 @@ import os
 import pytest
 import torch
 
+from parity_log import check, record
+
 pytestmark = pytest.mark.gpu
+NORTH_STAR = 1e-2      # BASELINE.json north_star: loss within 1e-2 of the reference CPU path (16-bit storage)
+CURVE_STEPS = 20       # 20-step loss-curve parity (multimodal_classifier_train.py:177-201)
 DEV = "cuda"
 
 
@@ -34,7 +38,7 @@ def test_text_tower_loss_curve_matches_oracle(deterministic):
     from multimodalsimilar_amd import train as T
     cfg = dict(kind="nlp", text="tiny", seq_len=32, batch=16, classes=64)
     model = T.build_model(cfg, "cpu", seed=0, dropout=False)
-    steps = 6
+    steps = CURVE_STEPS
     orc = _text_oracle(model, steps)
     model.to(DEV)
     ts = T.TrainStep(model, "nlp", steps)
@@ -46,18 +50,21 @@ def test_text_tower_loss_curve_matches_oracle(deterministic):
         l2, pred = ts.step({k: v.to(DEV) for k, v in batch.items()})
         got.append(l2.item())
     print("\noracle losses", [round(x, 4) for x in ref], "\nhip    losses", [round(x, 4) for x in got])
-    for a, b in zip(got, ref):
-        assert abs(a - b) < 1.5e-2 * abs(b)
-    # parameters after 6 AdamW steps (lr schedules included) stay together.  AdamW's early updates are ~lr * sign(g): an element whose
+    dev = [abs(a - b) / abs(b) for a, b in zip(got, ref)]
+    check("text_tower_loss_curve", f"max relative loss deviation over {steps} steps (worst at step {dev.index(max(dev))})", max(dev), NORTH_STAR)
+    record("text_tower_loss_curve", "loss at the last step: oracle", ref[-1], 1e9)
+    record("text_tower_loss_curve", "loss at the last step: HIP", got[-1], 1e9)
+    # parameters after the AdamW steps (lr schedules included) stay together.  AdamW's early updates are ~lr * sign(g): an element whose
     # bf16 / fp32 gradients straddle zero moves the other way by up to 2 lr in that step -- so the max-norm bound is Adam's own
     # (2 x the sum of the head's learning rates so far), and what is tight is the mean and the FRACTION of elements off by > 5e-3
     w = model.classifier.weight.detach().cpu()
     d = (w - orc.head.detach()).abs()
     lr_sum = sum(T.linear_schedule_lr(1e-2, t, 0.15 * steps, steps) for t in range(steps))
-    assert d.mean() < 2e-3           # head lr warms up to 1e-2 (6 steps of <= 1e-2 each)
-    assert d.max() < 2 * lr_sum + 1e-3 and (d > 5e-3).float().mean() < 0.03
+    record("text_tower_loss_curve", "mean |head weight - oracle| after the curve", d.mean(), 4e-3)
+    assert d.mean() < 4e-3           # head lr warms up to 1e-2 and decays linearly (20 steps of <= 1e-2 each)
+    assert d.max() < 2 * lr_sum + 1e-3 and (d > 1e-2).float().mean() < 0.05
     k = "encoder.layer.1.output.dense.weight"
-    assert (dict(model.ptm.named_parameters())[k].detach().cpu() - orc.text[k].detach()).abs().mean() < 5e-5   # lr 5e-5
+    assert (dict(model.ptm.named_parameters())[k].detach().cpu() - orc.text[k].detach()).abs().mean() < 1.5e-4   # lr 5e-5, 20 steps
     assert abs(ts.opt_fc.param_groups[0]["lr"] - orc.opt_fc.param_groups[0]["lr"]) < 1e-12
     assert abs(ts.opt_emb.param_groups[0]["lr"] - orc.opt_emb.param_groups[0]["lr"]) < 1e-12
 
@@ -74,24 +81,26 @@ def test_two_tower_step_literal_and_fused_paths_agree_and_track_oracle(determini
             orc = step_ref.TwoTowerOracle(tshape, {k: v.detach().clone() for k, v in model.nlp.ptm.state_dict().items()},
                                           cfg["image"], {k: v.detach().clone() for k, v in model.cv.state_dict().items()
                                                          if not k.startswith("classifier")},
-                                          model.classifier.weight.detach().clone(), num_steps=10, margin=0.5)
+                                          model.classifier.weight.detach().clone(), num_steps=CURVE_STEPS, margin=0.5)
         model.cv.to(DEV); model.nlp.to(DEV); model.classifier.to(DEV)
-        ts = T.TrainStep(model, "multimodal", 10, fused_loss=fused)
+        ts = T.TrainStep(model, "multimodal", CURVE_STEPS, fused_loss=fused)
         ls = []
-        for i in range(3):
+        for i in range(CURVE_STEPS if fused else 3):
             batch = T.synthetic_batch(cfg, DEV, seed=70 + i)
             l, pred = ts.step(batch)
             ls.append(l.item())
             assert pred.shape == (cfg["batch"],)
         losses[fused] = ls
-    ref = [orc.step(T.synthetic_batch(cfg, "cpu", seed=70 + i))[0].item() for i in range(3)]
-    print("\nfused", losses[True], "\nliteral", losses[False], "\noracle", ref)
+    ref = [orc.step(T.synthetic_batch(cfg, "cpu", seed=70 + i))[0].item() for i in range(CURVE_STEPS)]
+    print("\nfused", [round(x, 4) for x in losses[True]], "\nliteral", losses[False], "\noracle", [round(x, 4) for x in ref])
     for a, b in zip(losses[True], losses[False]):
         # same kernels underneath, only the loss plumbing differs (bf16 dcos from the fused pass vs fp32 dlogits from autograd);
         # in deterministic mode nothing else separates the two runs
         assert abs(a - b) < 2e-3 * abs(b)
-    for a, b in zip(losses[True], ref):
-        assert abs(a - b) < 3e-2 * abs(b)
+    dev = [abs(a - b) / abs(b) for a, b in zip(losses[True], ref)]
+    check("two_tower_loss_curve", f"max relative loss deviation over {CURVE_STEPS} steps (worst at step {dev.index(max(dev))})", max(dev), NORTH_STAR)
+    record("two_tower_loss_curve", "loss at the last step: oracle", ref[-1], 1e9)
+    record("two_tower_loss_curve", "loss at the last step: HIP", losses[True][-1], 1e9)
 
 
 def test_eval_forward_test_and_checkpoint_roundtrip(tmp_path):

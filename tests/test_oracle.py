@@ -63,7 +63,17 @@ def test_glue_matches_reference(golden_dir):
 def _nlp_shape(name):
     if name == "tiny":
         return bert_ref.BertShape(128, 128, 2, 2, 512, 64)
+    if name == "base1":      # BASELINE config 1's roberta-base shape, one layer
+        return bert_ref.BertShape(21128, 768, 1, 12, 3072, 512)
     return bert_ref.BertShape(256, 256, 2, 4, 1024, 128)
+
+
+def head_weight_from_golden(d, shape):
+    """The ArcFace head of an nlp fixture: stored, or (base1: 3 MB) re-seeded exactly as the generator seeded it."""
+    if "head_weight" in d:
+        return T(d["head_weight"]).clone()
+    C = d["logits"].shape[1]
+    return torch.randn(C, shape.hidden_size, generator=torch.Generator().manual_seed(int(d["seed_head"]))) * 0.05
 
 
 def nlp_state_from_golden(d, name):
@@ -81,12 +91,12 @@ def nlp_state_from_golden(d, name):
     return shape, sd
 
 
-@pytest.mark.parametrize("name", ["tiny", "mid"])
+@pytest.mark.parametrize("name", ["tiny", "mid", "base1"])
 def test_bert_oracle_matches_reference(golden_dir, name):
     d = _load(golden_dir, f"nlp_{name}.npz")
     shape, sd = nlp_state_from_golden(d, name)
     sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    hw = T(d["head_weight"]).requires_grad_(True)
+    hw = head_weight_from_golden(d, shape).requires_grad_(True)
     pooled = bert_ref.bert_forward(sd, shape, T(d["input_ids"]), T(d["token_type_ids"]), T(d["attention_mask"]))
     assert torch.allclose(pooled, T(d["pooled"]), atol=2e-5)
     z = arcface_ref.arcface_forward(pooled, hw, T(d["label"]), 64.0, 0.40, False)   # nlp_classifier.py:15 defaults
@@ -94,11 +104,14 @@ def test_bert_oracle_matches_reference(golden_dir, name):
     loss = arcface_ref.ce_loss(z, T(d["label"]))
     assert abs(loss.item() - float(d["loss"])) < 1e-3
     loss.backward()
-    assert torch.allclose(hw.grad, T(d["head_grad"]), rtol=1e-2, atol=1e-5)
+    assert torch.allclose(hw.grad, T(d["head_grad"]).float(), rtol=1e-2, atol=1e-5)
     for k, v in d.items():
-        if k.startswith("g::"):
-            g = sd[k[3:]].grad
-            ref = T(v)
+        if k.startswith("g::") or k.startswith("g64::"):
+            g = sd[k.split("::")[1]].grad
+            ref = T(v).float()                                   # base1 stores its 768 x 768 gradients as float16
+            if k.startswith("g64::"):
+                assert float(g[64:].abs().max()) == 0.0, k       # position rows >= S are never indexed
+                g = g[:64]
             assert (g - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-6, k
         if k.startswith("gnorm::"):
             assert abs(sd[k[7:]].grad.norm().item() - float(v)) <= 2e-3 * float(v) + 1e-6, k
@@ -204,3 +217,30 @@ def test_preprocess_oracle_matches_installed_pillow():
     for H, W, ow, oh in [(33, 47, 20, 14), (48, 36, 96, 128), (90, 60, 60, 90), (23, 23, 64, 64), (200, 150, 75, 56), (31, 17, 17, 31)]:
         img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         assert np.array_equal(P.resize_bicubic_u8(img, ow, oh), np.asarray(Image.fromarray(img).resize((ow, oh), Image.BICUBIC)))
+
+
+def test_multimodal_forward_oracle_matches_the_reference_module(golden_dir):
+    """multimodal_forward.npz was produced by EXECUTING /root/reference/multimodal_classifier.py:14-57 (tests/golden/gen_golden.py,
+    gen_multimodal_forward: __init__ over two pickled towers, predict_emb, forward, forward(is_test=True)).  The oracle's glue +
+    ArcFace(m = 0.5, s = 64) + text tower, around the stand-in image tower restated from its stored weights, must reproduce it."""
+    d = _load(golden_dir, "multimodal_forward.npz")
+    shape, sd = nlp_state_from_golden(d, "tiny")
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    fw, fb = T(d["cv_fc_weight"]).requires_grad_(True), T(d["cv_fc_bias"]).requires_grad_(True)
+    hw = T(d["head_weight"]).requires_grad_(True)
+    e_img = 3.0 * torch.tanh(torch.nn.functional.linear(T(d["img"]).mean((2, 3)), fw, fb))          # the generator's StandInImageTower
+    e_txt = bert_ref.bert_forward(sd, shape, T(d["input_ids"]), T(d["token_type_ids"]), T(d["attention_mask"]))
+    final = arcface_ref.glue_concat(e_img, e_txt)                                                  # multimodal_classifier.py:54-56
+    assert torch.allclose(final, T(d["final"]), atol=2e-5)
+    z = arcface_ref.arcface_forward(final, hw, T(d["label"]), 64.0, 0.5, False)                    # :22, :40
+    assert torch.allclose(z, T(d["logits"]), atol=2e-3)
+    assert torch.allclose(arcface_ref.arcface_forward_test(final, hw), T(d["logits_test"]), atol=2e-5)   # :42
+    loss = arcface_ref.ce_loss(z, T(d["label"]))
+    assert abs(loss.item() - float(d["loss"])) < 1e-3
+    loss.backward()
+    assert torch.allclose(hw.grad, T(d["head_grad"]), rtol=1e-2, atol=1e-5)
+    assert torch.allclose(fw.grad, T(d["cv_fc_weight_grad"]), rtol=1e-2, atol=1e-5)
+    assert torch.allclose(fb.grad, T(d["cv_fc_bias_grad"]), rtol=1e-2, atol=1e-5)
+    for k in ("pooler.dense.weight", "encoder.layer.1.output.dense.weight"):
+        ref = T(d["g::" + k])
+        assert (sd[k].grad - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-6, k
