@@ -246,9 +246,18 @@ def main():
     # graph, so with the graph path they are taken over the same number of EAGER steps right after the timed region (the graph
     # replays exactly these kernels; the rocprofv3 summary under profiles/ is of the replayed graph itself).
     roof_from = "the timed region"
+    eager_ms = None
     if gstep is not None:
         gstep.close()
+        # the EAGER step (one Python launch per kernel) is what every data-parallel run executes (collectives are not captured):
+        # timed here in the same process, on the same box, right after the graph replay, and reported beside it
         step.step(batch)
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        for _ in range(min(args.steps, 5)):
+            step.step(batch)
+        torch.cuda.synchronize()
+        eager_ms = 1e3 * (time.perf_counter() - te) / min(args.steps, 5)
         timer.on = True
         for _ in range(min(args.steps, 5)):
             step.step(batch)
@@ -296,12 +305,14 @@ def main():
                        "algorithmic_gflop_per_pair": fpp / 1e9,
                        "step_mfma_frac": (fpp * cfg["batch"] / (ms * 1e-3) / 1e12) / MFMA_BF16_PEAK_TFLOPS,
                        "final_loss": lossv, "launch": launch,
+                       # the same step launched kernel by kernel from Python (what N > 1 ranks run), same process / box, after the timed region
+                       "eager_ms_per_step": eager_ms,
                        # every MMSIM_* switch set in this process (they select schedules / kernels): empty = the defaults
                        "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MMSIM_")}},
             "roofline": None if g is None else {
                 "bound": "mfma", "kernel": "gemm_pp64_kernel<false,true,256> (Y = X W^T: 256x256 tiles, 64-deep LDS-DMA slices, ping-pong wave groups, bf16 MFMA 16x16x32, fp32 accumulate)",
                 "achieved": g["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": _pmc_traffic(args.config)[0], "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc_gemm_pp64.json)",
+                "traffic": _pmc_traffic(args.config)[0], "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc_gemm_pp64.json: the text tower's kernels and shapes are unchanged since)",
                 "algorithmic_bytes_per_launch": _pmc_traffic(args.config)[1],
                 "launches": g["launches"], "avg_launch_us": g["avg_us"], "measured_over": roof_from,
                 "concurrent_with": "image-tower kernels on a second stream" if g_excl else None,

@@ -20,6 +20,15 @@
 #define ATTN_BWD_WAVES 2
 #endif
 #define DST_PITCH 80    // bytes, dS^T image rows of 32 bf16
+#ifndef ATTN_BWD_DS2
+#define ATTN_BWD_DS2 1        // two dS^T images (alternating per query tile): the barrier after the dQ products is not needed
+#endif
+#ifndef ATTN_BWD_KLDS
+#define ATTN_BWD_KLDS 1       // K^T fragments of the S / dS products read from the LDS image instead of held in 16 registers
+#endif                        //   (measured at B = 256, S = 128, 16 heads: 158 -> 148 us; two dS^T images alone: no change)
+#ifndef ATTN_BWD_MFMA_COLSUM
+#define ATTN_BWD_MFMA_COLSUM 1   // v-bias column sums as ones x dV on the matrix cores (transposing reads of the dV image); 0: 2-byte LDS reads
+#endif
 
 struct AttnParams {
   const bf16* qkv; const int64_t* mask; bf16* ctx; const bf16* dctx; float* lse; bf16* dqkv;
@@ -162,8 +171,8 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
   char* Qt = smem;                          // [2][32][ROW_PITCH]
   char* Ot = smem + 2 * TILE;               // dO, [2][32][ROW_PITCH]
   char* Ks = smem + 4 * TILE;               // K [S][ROW_PITCH]
-  char* Ds = Ks + S * ROW_PITCH;            // dS^T [S keys][DST_PITCH] for the current query tile
-  float* fl = reinterpret_cast<float*>(Ds + S * DST_PITCH);
+  char* Ds0 = Ks + S * ROW_PITCH;           // dS^T [S keys][DST_PITCH] for the current query tile (x2 with ATTN_BWD_DS2)
+  float* fl = reinterpret_cast<float*>(Ds0 + (ATTN_BWD_DS2 ? 2 : 1) * S * DST_PITCH);
   float* lse = fl; float* dlt = fl + S; float* mb = fl + S + 64;     // dlt: [2][32] delta of the staged tiles
   float* cb = fl + 2 * S + 64;              // [NT][192] column sums of this (b, h)'s dq | dk | dv (bias gradient of the QKV projection),
                                             // one slot per wave: each wave adds into its own in program order, the slots are summed in wave order
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
   bf8 kreg[4], vreg[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    kreg[kk] = *reinterpret_cast<const bf8*>(base + (size_t)key * p.ld_qkv + p.H + 16 * kk + 8 * hh);
+    if (!ATTN_BWD_KLDS) kreg[kk] = *reinterpret_cast<const bf8*>(base + (size_t)key * p.ld_qkv + p.H + 16 * kk + 8 * hh);
     vreg[kk] = *reinterpret_cast<const bf8*>(base + (size_t)key * p.ld_qkv + 2 * p.H + 16 * kk + 8 * hh);
   }
   park(0);
@@ -247,6 +256,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
     const char* Qs = Qt + cur * TILE;       // rows of this query tile
     const char* Os = Ot + cur * TILE;
     const float* dl = dlt + cur * 32;
+    char* Ds = Ds0 + (ATTN_BWD_DS2 ? cur * S * DST_PITCH : 0);
     if (qt + 1 < NT) issue(qt + 1);
     f16v X, dP;
 #pragma unroll
@@ -256,6 +266,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
       const int off = (lane & 31) * ROW_PITCH + (16 * kk + 8 * hh) * 2;
       const bf8 qa = *reinterpret_cast<const bf8*>(Qs + off);
       const bf8 oa = *reinterpret_cast<const bf8*>(Os + off);
+      if (ATTN_BWD_KLDS) kreg[kk] = *reinterpret_cast<const bf8*>(Ks + key * ROW_PITCH + (16 * kk + 8 * hh) * 2);
       X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kreg[kk], X, 0, 0, 0);
       dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vreg[kk], dP, 0, 0, 0);
     }
@@ -323,8 +334,11 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
 #pragma unroll
       for (int e = 0; e < 4; ++e) cq[t][e] += bf2f(o[e]);
     }
-    __syncthreads();
+    // one dS^T image: the next tile's writes must wait for these reads.  Two images: the image written next was last read before
+    // the barrier above of the PREVIOUS iteration, the Q / dO buffer parked next was last read before this iteration's barrier
+    if (!ATTN_BWD_DS2) __syncthreads();
   }
+  if (ATTN_BWD_DS2) __syncthreads();         // the K image and tile buffers are reused below
   // dK, dV leave through LDS (the K image and the Q / dO tile buffers are free after the loop's last barrier): the
   // accumulators hold 4 channels of one key per register quad -- written straight out that is 8-byte pieces of 32 different
   // cache lines per store; from the [key][64] images every row leaves as one 128-byte line, and the column sums for the k | v
@@ -354,7 +368,30 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
       *reinterpret_cast<uint4*>(dkg + (size_t)row * p.ld_qkv + p.H + ch * 8) = vq;
     }
   }
-  if (p.dbias_parts) {          // sums of the ROUNDED values: thread = (column, wave's 32 keys)
+  if (p.dbias_parts && ATTN_BWD_MFMA_COLSUM) {
+    // key / value bias gradients: column sums of the ROUNDED dK / dV images as (all-ones [16 x 32 keys]) x image[32 keys x 16 d] on
+    // the matrix cores -- this wave's 32 keys, four 16-column blocks per image: 8 MFMAs + 16 transposing reads per wave instead of
+    // 64 two-byte LDS reads per lane.  Every row of the product is the same sum: row 0 is kept.  (The key-bias sum is analytically
+    // zero -- softmax is invariant to a per-query constant -- and what is summed here is the rounding noise of the stored dK, as the
+    // reference's autograd sums its own; kept so that dbias == column sums of the tensor that was written, exactly.)
+    bf8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+#pragma unroll
+    for (int d4 = 0; d4 < 4; ++d4) {
+      f4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+      ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag16(dKs, ROW_PITCH, 32 * w, 16 * d4, lane), ones, ak, 0, 0, 0);
+      av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag16(dVs, ROW_PITCH, 32 * w, 16 * d4, lane), ones, av, 0, 0, 0);
+      // operands swapped as everywhere here: acc[e] = C[m = lane & 15][n = 16 d4 + 4 (lane >> 4) + e], all rows m equal
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          cb[192 * w + 64 + 16 * d4 + 4 * (lane >> 4) + e] += ak[e];
+          cb[192 * w + 128 + 16 * d4 + 4 * (lane >> 4) + e] += av[e];
+        }
+      }
+    }
+  } else if (p.dbias_parts) {          // sums of the ROUNDED values: thread = (column, wave's 32 keys)
     const int d = lane, k0 = 32 * w;
     float sk = 0.f, sv = 0.f;
 #pragma unroll 8
@@ -420,7 +457,7 @@ extern "C" int mmsim_attn_fwd(const void* qkv, int ld_qkv, const long long* mask
 }
 
 static size_t attn_bwd_lds(int S) {      // Q / dO tile pairs + K image + dS^T image + lse[S], delta[2][32], mask[S], bias sums[192]
-  return (size_t)4 * 32 * ROW_PITCH + (size_t)S * (ROW_PITCH + DST_PITCH) + (size_t)(2 * S + 64 + 192 * (S / 32)) * 4;      // bias sums: one [192] slot per wave
+  return (size_t)4 * 32 * ROW_PITCH + (size_t)S * (ROW_PITCH + (ATTN_BWD_DS2 ? 2 : 1) * DST_PITCH) + (size_t)(2 * S + 64 + 192 * (S / 32)) * 4;      // bias sums: one [192] slot per wave
 }
 
 static int attn_bwd_impl(const void* qkv, int ld_qkv, const long long* mask, const void* ctx, const void* dctx, int ld_ctx,

@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_pair_kernel(GemmParams p1, Ge
 
 // C-ABI -- see include/mmsim_hip.h for the contract.
 bool gemm_fast_eligible(const GemmParams& p, int splits);
+bool gemm_fast_rowfix(const GemmParams& p, int splits, int trans_a, int b_kmajor);
 void gemm_fast_launch(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s);
 
 static bool force_generic() {
@@ -396,7 +397,7 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   hipStream_t s = (hipStream_t)stream;
   MMSIM_REQUIRE(!colsum || (trans_a && !b_kmajor && xf_operand == 0 && !stats && fmt == 0 && !force_generic() && gemm_fast_eligible(p, splits)),
                 "gemm: the fused column sum needs the pipelined weight-gradient kernel");
-  if (xf_operand == 0 && !stats && fmt == 0 && !force_generic() && gemm_fast_eligible(p, splits)) {
+  if (xf_operand == 0 && !stats && fmt == 0 && !force_generic() && (gemm_fast_eligible(p, splits) || gemm_fast_rowfix(p, splits, trans_a, b_kmajor))) {
     if (g_group.active) { const int rc = group_flush(); if (rc) return rc; }
     gemm_fast_launch(p, trans_a, b_kmajor, splits, s);
     return mmsim_check_launch("gemm_bf16_fast");

@@ -365,6 +365,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
       fast_epilogue<EPI_NONE, 3>(q, a4, row0, col0, lane, fs, stg);
     }
     else if (p.atomic) fast_epilogue<EPI_NONE, 3>(p, a4, row0, col0, lane, fs, stg);
+    else if (TA && !TB_KMAJOR && BN == 256 && !GRP && p.epi == EPI_ROWFIX) {
+      // the ArcFace weight gradient (head.py): rows past M (the class count is not a multiple of 256) are predicated
+      if (p.accum) fast_epilogue<EPI_ROWFIX, 2, true>(p, a4, row0, col0, lane, fs, stg);
+      else fast_epilogue<EPI_ROWFIX, 1, true>(p, a4, row0, col0, lane, fs, stg);
+    }
     else if (p.accum) fast_epilogue<EPI_NONE, 2>(p, a4, row0, col0, lane, fs, stg);
     else if (p.epi == EPI_TANH) fast_epilogue<EPI_TANH, 1>(p, a4, row0, col0, lane, fs, stg);
     else fast_epilogue<EPI_NONE, 1>(p, a4, row0, col0, lane, fs, stg);
@@ -373,6 +378,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
   if constexpr (MT == 8) epi_half(*reinterpret_cast<f4 (*)[4][4]>(&acc[4][0]), 1);
 }
 
+// The row-fix weight gradient (EPI_ROWFIX: C[M,N] f32 = r[m] (A^T B - aux r'[m]), the ArcFace head's dW with the backward of
+// F.normalize folded in) on the pipelined 256 x 256 kernel although M (the class count) is not a multiple of 256: A is stored
+// [K][lda] with lda covering M rounded up to 256 (head.py pads the class dimension of dcos with zero columns), so the operand
+// tiles are read whole and only the epilogue predicates rows >= M.  It is a pure output stream (1.1 GB of fp32 at 100 000 x 2816,
+// K = 256): the generic 128 x 128 kernel ran it at 1.5 TB/s.
+static bool rowfix_eligible(const GemmParams& p, int splits) {
+  return p.epi == EPI_ROWFIX && p.c_f32 && splits == 1 && !p.atomic && (p.N % 256) == 0 && (p.K % 64) == 0 && p.K >= 128 &&
+         p.lda >= ((p.M + GBM - 1) / GBM) * GBM && (p.ld_aux % 4) == 0 && ((p.M + GBM - 1) / GBM) * (p.N / 256) >= 128;
+}
 static bool pipe_eligible(const GemmParams& p, int splits, int bn) {
   if (p.M % GBM || p.N % bn || p.K % 64 || p.k_per_split % 64) return false;
   return (p.M / GBM) * (p.N / bn) * splits >= 128;        // enough blocks to fill the chip
@@ -383,8 +397,9 @@ static bool fast128_eligible(const GemmParams& p, int splits) {
   return true;
 }
 
+bool gemm_fast_rowfix(const GemmParams& p, int splits, int trans_a, int b_kmajor) { return trans_a && !b_kmajor && rowfix_eligible(p, splits); }
 bool gemm_fast_eligible(const GemmParams& p, int splits) {
-  if (p.c_f32 && !(p.epi == EPI_NONE || p.epi == EPI_TANH)) return false;   // f32 outputs: plain / tanh only
+  if (p.c_f32 && !(p.epi == EPI_NONE || p.epi == EPI_TANH)) return false;   // f32 outputs: plain / tanh only (row-fix: gemm_fast_rowfix)
   if ((p.ldc % 4) || (p.ld_aux % 4)) return false;
   if ((long long)p.k_per_split * splits < p.K) return false;
   return pipe_eligible(p, splits, 256) || pipe_eligible(p, splits, 128) || fast128_eligible(p, splits);
@@ -398,7 +413,7 @@ static int tile_pref() {      // MMSIM_GEMM_TILE: 0 auto (default), 1 = old 256x
 
 template <int BN>
 static void launch_pipe(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s) {
-  p.tiles_m = p.M / GBM; p.tiles_n = p.N / BN; p.splits = splits;
+  p.tiles_m = (p.M + GBM - 1) / GBM; p.tiles_n = p.N / BN; p.splits = splits;      // M % 256 != 0 only for the row-fix product (rowfix_eligible)
   dim3 grid(p.tiles_m * p.tiles_n * splits), block(512);
   // 160 KiB: A ring 3 x 32 KiB + B ring 2 x (BN x 128 B); never less than the epilogue staging (8 waves x 64 x 68 floats)
   const size_t lds_stage = 8 * 64 * EP_PITCH * 4, lds_ring = 3 * GBM * 128 + 2 * BN * 128;
@@ -424,7 +439,7 @@ static void launch_pipe(GemmParams p, int trans_a, int b_kmajor, int splits, hip
 }
 
 void gemm_fast_launch(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s) {
-  if (p.colsum) { launch_pipe<256>(p, trans_a, b_kmajor, splits, s); return; }      // only this kernel sums the columns (host checked the shape)
+  if (p.colsum || (p.epi == EPI_ROWFIX && p.c_f32)) { launch_pipe<256>(p, trans_a, b_kmajor, splits, s); return; }      // only this kernel sums the columns (host checked the shape)
   const int pref = tile_pref();
   // wgrad-shaped products (A transposed: few output tiles, long reduction, split-K) take the narrower tile: more tiles
   // per split and half the atomic traffic per block; everything else prefers 256x256 (twice the flop per staged byte)

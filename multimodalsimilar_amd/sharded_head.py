@@ -50,6 +50,8 @@ class ShardedArcMarginProduct(ArcMarginProduct):
         c0, cl = shard_range(out_feature, world, rank)
         if cl <= 0:
             raise ValueError(f"ShardedArcMarginProduct: rank {rank} of {world} would own no class of {out_feature}")
+        if out_feature >= 1 << 24:
+            raise ValueError("ShardedArcMarginProduct: class indices travel as fp32 columns of the gathered rows (exact below 2^24)")
         super().__init__(in_feature, cl, s=s, m=m, easy_margin=easy_margin)
         self.pg, self.world, self.rank = process_group, world, rank
         self.class_offset, self.local_classes, self.total_classes = c0, cl, out_feature
@@ -85,6 +87,11 @@ class ShardedArcMarginProduct(ArcMarginProduct):
             return t.unsqueeze(0)
         stage = t.is_cuda and dist.get_backend(self.pg) == "gloo"
         src = t.cpu() if stage else t.contiguous()
+        if dist.get_backend(self.pg) == "nccl":
+            # RCCL: ONE collective into one [world, ...] tensor (no list of per-rank outputs, no torch.stack copy afterwards)
+            out = torch.empty((self.world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+            dist.all_gather_into_tensor(out, src, group=self.pg)
+            return out
         outs = [torch.empty_like(src) for _ in range(self.world)]
         dist.all_gather(outs, src, group=self.pg)
         out = torch.stack(outs)
@@ -181,11 +188,15 @@ class _ShardedLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, mod, label):
         B, N = x.shape[0], mod.world
-        X = mod._gather(x.contiguous().float()).reshape(N * B, -1)
-        Y = mod._gather(label.contiguous()).reshape(N * B)
+        # TWO collectives in the forward (were four): the labels ride as one more fp32 column of the embeddings, the local argmax
+        # as a fifth column of the row statistics -- class indices are < 2^24 and therefore exact in fp32 (checked in __init__)
+        XY = mod._gather(torch.cat([x.contiguous().float(), label.contiguous().float().unsqueeze(1)], 1))      # [N, B, D + 1]
+        X = XY[..., :-1].reshape(N * B, -1).contiguous()
+        Y = XY[..., -1].reshape(N * B).to(torch.int64).contiguous()
         cos, st = mod._local_cosines(X)
         stats, arg = mod._partial_stats(cos, st, Y)
-        lse, zt, amax = combine_row_stats(mod._gather(stats), mod._gather(arg))
+        SA = mod._gather(torch.cat([stats, arg.float().unsqueeze(1)], 1))                                       # [N, N*B, 5]
+        lse, zt, amax = combine_row_stats(SA[..., :4], SA[..., 4].to(torch.int64))
         rows = slice(mod.rank * B, (mod.rank + 1) * B)
         ctx.mod, ctx.st, ctx.cos, ctx.Y, ctx.lse, ctx.B = mod, st, cos, Y, lse.contiguous(), B
         out_arg = amax[rows].contiguous()
