@@ -193,6 +193,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, ch
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
+  // One K-step of register-staged prefetch.  Two steps ahead (a second register set, loop unrolled by two) was built and measured
+  // on the image tower's late-stage shapes (tools/bench_imgemm2.py, operands from HBM): 6.25 vs 5.75 ms over the 20 blocks -- SLOWER
+  // (254-256 VGPRs, hipcc waits for the younger set's loads before parking the older one); removed.
   uint4 ra[4], rb[4];
   XfGate xg;
   load_tile<TA>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
