@@ -81,8 +81,8 @@ def test_bert_large_layer_at_cfg3_shape_matches_the_oracle():
     assert (am.cpu()[clear] == ref_logits.argmax(1)[clear]).all()
     named = dict(model.ptm.named_parameters())
     worst = max(l2err(named[k].grad, sdr[k].grad) for k in keys)
-    check(tag, "worst parameter gradient relative L2 (11 tensors)", worst, 5e-2)
-    check(tag, "head gradient relative L2", l2err(model.classifier.weight.grad, hw.grad), 3e-2)
+    check(tag, "worst parameter gradient relative L2 (11 tensors)", worst, 2e-2)
+    check(tag, "head gradient relative L2", l2err(model.classifier.weight.grad, hw.grad), 1.5e-2)
 
 
 def test_head_at_cfg4_shape_matches_the_oracle():
@@ -112,10 +112,10 @@ def test_head_at_cfg4_shape_matches_the_oracle():
     check(tag, "loss relative error", abs(loss.item() - ref.item()) / ref.item(), 2e-3)
     record(tag, "argmax agreement over 256 rows", (am.cpu() == logits.argmax(1)).float().mean(), 2.0)
     assert (am.cpu() == logits.argmax(1)).float().mean() > 0.98
-    check(tag, "dx relative L2", l2err(xd.grad, xr.grad), 2e-2)
+    check(tag, "dx relative L2", l2err(xd.grad, xr.grad), 1e-2)
     rows = torch.cat([y[:32], torch.randint(0, C, (64,), generator=g)])
     assert l2err(head.weight.grad.cpu()[rows], W.grad[rows]) < 2e-2
-    check(tag, "dW relative L2", l2err(head.weight.grad, W.grad), 2e-2)
+    check(tag, "dW relative L2", l2err(head.weight.grad, W.grad), 1e-2)
     cos = head.forward_test(xd.detach())
     check(tag, "max |forward_test cosine - oracle|", (cos.cpu() - arcface_ref.arcface_forward_test(x, W.detach())).abs().max(), 6e-3)
     # the literal API path at this shape: materialised margin logits
