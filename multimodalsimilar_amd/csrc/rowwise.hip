@@ -254,6 +254,94 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16* t, const bf
   }
 }
 
+// The same with 8 columns per lane per 512-column chunk (16-byte accesses) and TWO rows per wave in flight (H % 8 == 0, H <= 1024: the
+// text tower): the one-row form above keeps 8 bytes per lane per stream in flight and ran at 4.7 TB/s on [32768, 1024].
+#ifndef ADD_LN_FWD8
+#define ADD_LN_FWD8 1
+#endif
+template <int NC>      // NC = ceil(H / 512)
+__global__ __launch_bounds__(256) void add_ln_fwd8_kernel(const bf16* __restrict__ t, const bf16* __restrict__ resid, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, bf16* __restrict__ y, bf16* __restrict__ hout,
+                                                          float* mean_o, float* rstd_o, int M, int H, float eps, Drop dr) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row0 = (blockIdx.x * 4 + wv) * 2;
+  if (row0 >= M) return;
+  const bool two = row0 + 1 < M;
+  bf8 tv[2][NC], rv[2][NC];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const size_t base = (size_t)(row0 + (q && two ? 1 : 0)) * H;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = lane * 8 + c * 512;
+      if (col < H) {
+        tv[q][c] = __builtin_nontemporal_load(reinterpret_cast<const bf8*>(t + base + col));      // the dense output: read once
+        rv[q][c] = *reinterpret_cast<const bf8*>(resid + base + col);
+      }
+    }
+  }
+  float v[2][NC][8], s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const size_t base = (size_t)(row0 + (q && two ? 1 : 0)) * H;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = lane * 8 + c * 512;
+      if (col < H) {
+        float4 a0 = make_float4(bf2f(tv[q][c][0]), bf2f(tv[q][c][1]), bf2f(tv[q][c][2]), bf2f(tv[q][c][3]));
+        float4 a1 = make_float4(bf2f(tv[q][c][4]), bf2f(tv[q][c][5]), bf2f(tv[q][c][6]), bf2f(tv[q][c][7]));
+        a0 = drop4(a0, dr, (unsigned long long)base + col);
+        a1 = drop4(a1, dr, (unsigned long long)base + col + 4);
+        const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        bf8 rb;      // statistics are taken on the bf16-rounded sum that backward will read back
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { rb[e] = f2bf(a[e] + bf2f(rv[q][c][e])); v[q][c][e] = bf2f(rb[e]); s[q] += v[q][c][e]; }
+        if (q == 0 || two) __builtin_nontemporal_store(rb, reinterpret_cast<bf8*>(y + base + col));      // read again only in backward
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[q][c][e] = 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s[0] += __shfl_xor(s[0], o, 64); s[1] += __shfl_xor(s[1], o, 64); }
+  const float mean[2] = {s[0] / H, s[1] / H};
+  float qq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = lane * 8 + c * 512;
+      if (col < H) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[q][c][e] - mean[q]; qq[q] += d * d; }
+      }
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { qq[0] += __shfl_xor(qq[0], o, 64); qq[1] += __shfl_xor(qq[1], o, 64); }
+  const float rstd[2] = {rsqrtf(qq[0] / H + eps), rsqrtf(qq[1] / H + eps)};
+  if (lane == 0) {
+    mean_o[row0] = mean[0]; rstd_o[row0] = rstd[0];
+    if (two) { mean_o[row0 + 1] = mean[1]; rstd_o[row0 + 1] = rstd[1]; }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = lane * 8 + c * 512;
+    if (col < H) {
+      const float4 g0 = ld4(gamma + col), g1 = ld4(gamma + col + 4), b0 = ld4(beta + col), b1 = ld4(beta + col + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (q == 1 && !two) break;
+        bf8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf((v[q][c][e] - mean[q]) * rstd[q] * g[e] + bb[e]);
+        *reinterpret_cast<bf8*>(hout + (size_t)(row0 + q) * H + col) = o;      // the next GEMM's A operand: cached store
+      }
+    }
+  }
+}
+
 // LayerNorm backward.  dh = dh_a (+ dh_b).  Outputs dy (gradient of the pre-LN sum: goes to the residual
 // branch) and dt = dropout-mask(dy) (gradient of the dense output; same buffer as dy when p == 0), plus
 // column sums: dgamma, dbeta, dbias (= colsum dt).
@@ -362,6 +450,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dh_a, const bf1
 
 // 8 columns per lane per 512-column chunk (16-byte loads / stores) and TWO rows per wave in flight: the one-row form
 // above is latency-bound (each row is load -> two wave reductions -> store, 8 bytes per lane per stream in flight).
+// (Round 3: a one-row, next-row-prefetched form at three waves per SIMD -- 162 VGPRs instead of 236 -- measured the same 72-74 us on
+// [32768, 1024] with dropout, tools/bench_ln.py; not kept.)
 template <int NC>      // NC = ceil(H / 512)
 __global__ __launch_bounds__(256) void ln_bwd8_kernel(const bf16* __restrict__ dh_a, const bf16* __restrict__ dh_b, const bf16* __restrict__ y,
                                                       const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
@@ -604,6 +694,14 @@ extern "C" int mmsim_add_ln_fwd(const void* t, const void* resid, const float* g
                                 unsigned long long seed, unsigned int stream_id, void* stream) {
   MMSIM_REQUIRE(t && resid && gamma && beta && y && h && mean && rstd, "add_ln_fwd: null operand");
   MMSIM_REQUIRE(H % 4 == 0 && H <= 256 * MAXC, "add_ln_fwd: H must be a multiple of 4 and <= 2048");
+  if (ADD_LN_FWD8 && (H % 8) == 0 && H <= 1024) {
+    const dim3 grid((M + 7) / 8);
+    if (H <= 512) hipLaunchKernelGGL((add_ln_fwd8_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)t, (const bf16*)resid,
+                                     gamma, beta, (bf16*)y, (bf16*)h, mean, rstd, M, H, eps, make_drop(dropout_p, seed, stream_id));
+    else hipLaunchKernelGGL((add_ln_fwd8_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)t, (const bf16*)resid,
+                            gamma, beta, (bf16*)y, (bf16*)h, mean, rstd, M, H, eps, make_drop(dropout_p, seed, stream_id));
+    return mmsim_check_launch("add_ln_fwd");
+  }
   hipLaunchKernelGGL(add_ln_fwd_kernel, ROWS_GRID(M), dim3(256), 0, (hipStream_t)stream, (const bf16*)t, (const bf16*)resid,
                      gamma, beta, (bf16*)y, (bf16*)h, mean, rstd, M, H, eps, make_drop(dropout_p, seed, stream_id));
   return mmsim_check_launch("add_ln_fwd");
