@@ -79,6 +79,26 @@ __device__ __forceinline__ void dma_tile(const bf16* __restrict__ X, int ld, int
   }
 }
 
+// one 1-KiB piece (piece i of the wave's NI) of the same tile: lets the caller place the pieces between other instructions
+template <bool TRANS, int ROWS>
+__device__ __forceinline__ void dma_piece(const bf16* __restrict__ X, int ld, int r0, int k0, char* lds, int wave, int lane, int i) {
+  constexpr int NI = ROWS * 128 / (8 * 1024);
+  const int blk = wave * NI + i;
+  const bf16* src;
+  if (!TRANS) {
+    const int row = blk * 8 + (lane >> 3), pos = lane & 7;
+    const int c = pos ^ ((row >> 1) & 7);
+    src = X + (size_t)(r0 + row) * ld + k0 + c * 8;
+  } else {
+    constexpr int CPR = ROWS / 8;
+    constexpr int RPB = 64 / CPR;
+    const int k = blk * RPB + lane / CPR, pc = lane % CPR;
+    const int c = (((pc >> 1) ^ ftr_key(k)) << 1) | (pc & 1);
+    src = X + (size_t)(k0 + k) * ld + r0 + c * 8;
+  }
+  __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(lds + blk * 1024), 16, 0, 0);
+}
+
 template <bool TRANS, int ROWS>
 __device__ __forceinline__ bf8 ffrag(const char* lds, int rbase, int ks, int lane) {
   if (!TRANS) {
@@ -173,6 +193,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p) {
 }
 
 #define GBM 256
+#ifndef PP64_A_IN_MFMA
+#define PP64_A_IN_MFMA 1          // gemm_pp64_kernel: A_{u+2}'s LDS-DMA pieces issued between the odd step's MFMAs (see the kernel)
+#endif
+#define PP64_B_IN_MFMA 0          // B_{u+1} cannot move the same way: it would be issued and awaited within one step
 
 // Main-loop ablation switches (no DMA / no MFMA / no epilogue) exist ONLY in the separately compiled ablation object
 // (-DMMSIM_ABLATE, tools/bench_gemm_abl.py builds it next to the product library): the product binary has no such code path.
@@ -307,19 +331,105 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     }                                                                                                    \
   }                                                                                                      \
   __builtin_amdgcn_sched_barrier(0);
+  // source addresses of this wave's four A pieces, kept in registers and advanced by one slice per issue (recomputing them among
+  // the MFMAs, with all fragments live, spilled): piece i of slice 2 first
+  const bf16* asrc[4];
+  {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int blk = wave * 4 + i;
+      if (!TA) {
+        const int row = blk * 8 + (lane >> 3), pos = lane & 7;
+        asrc[i] = gA + (size_t)(m0 + row) * glda + kbeg + 2 * 64 + (pos ^ ((row >> 1) & 7)) * 8;
+      } else {
+        const int k = blk * 2 + lane / 32, pc = lane % 32;      // GBM = 256: 32 chunks per k-row, 2 k-rows per 1-KiB block
+        asrc[i] = gA + (size_t)(kbeg + 2 * 64 + k) * glda + m0 + ((((pc >> 1) ^ ftr_key(k)) << 1) | (pc & 1)) * 8;
+      }
+    }
+  }
+  const size_t astep = TA ? (size_t)64 * glda : (size_t)64;
+  constexpr int B_LPU = BN * 128 / (8 * 1024);             // LDS-DMA pieces per wave per B unit (4 or 2)
+  const bf16* bsrc[B_LPU];                                 // the same for B: piece i of slice 1 first
+  {
+#pragma unroll
+    for (int i = 0; i < B_LPU; ++i) {
+      const int blk = wave * B_LPU + i;
+      if (TB_KMAJOR) {
+        const int row = blk * 8 + (lane >> 3), pos = lane & 7;
+        bsrc[i] = gB + (size_t)(n0 + row) * gldb + kbeg + 64 + (pos ^ ((row >> 1) & 7)) * 8;
+      } else {
+        constexpr int CPR = BN / 8, RPB = 64 / CPR;
+        const int k = blk * RPB + lane / CPR, pc = lane % CPR;
+        bsrc[i] = gB + (size_t)(kbeg + 64 + k) * gldb + n0 + ((((pc >> 1) ^ ftr_key(k)) << 1) | (pc & 1)) * 8;
+      }
+    }
+  }
+  const size_t bstep = TB_KMAJOR ? (size_t)64 : (size_t)64 * gldb;
+  // PP64_A_IN_MFMA: the four LDS-DMA pieces of A_{u+2} are issued BETWEEN the MFMAs of the odd step (one piece after every quarter
+  // of the wave's MFMAs) instead of in its load phase.  An LDS-DMA instruction costs 100-185 issue cycles inside a phase that
+  // already carries ds_read_b128s and other pieces, 25-60 in the gaps of an MFMA stream (MI355X_MICROARCH.md, "LDS-DMA piece issue
+  // cost"), and the load phases are what the partner wave's MFMA phase has to cover.  Order per wave unchanged (B_{u+1} in the even
+  // step, then A_{u+2}); the wait for slice u + 1 stays at the end of the odd step's LOAD phase (see there).
+#define PP64_MFMA_A() PP64_MFMA_X(doA, 4, asrc, astep, smem + sn * A_UNIT)
+#define PP64_MFMA_B() PP64_MFMA_X(doB, B_LPU, bsrc, bstep, smem + B_OFF + ((u + 1) & 1) * B_UNIT)
+#define PP64_MFMA_X(DOX, NPC, SRC, STEP, DST)                                                            \
+  __builtin_amdgcn_s_barrier();                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                     \
+  if (!(PP64_DBG(p) & 4)) {                                                                              \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);          \
+      if (((i + 1) % (MT / NPC)) == 0 && DOX) {          /* DOX: wave-uniform */                         \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)SRC[i / (MT / NPC)], (lds_void_ptr)(DST + (wave * NPC + i / (MT / NPC)) * 1024), 16, 0, 0); \
+        SRC[i / (MT / NPC)] += STEP;                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+      }                                                                                                  \
+    }                                                                                                    \
+    if constexpr (COLSUM_OK) {                                                                           \
+      if (do_colsum) {                                                                                   \
+        if (wn == 0) { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[0], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[1], bacc[1], 0, 0, 0); } \
+        else if (wn == 1) { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[2], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[3], bacc[1], 0, 0, 0); } \
+        else if (wn == 2) { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 4 : 0], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 5 : 1], bacc[1], 0, 0, 0); } \
+        else { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 6 : 2], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 7 : 3], bacc[1], 0, 0, 0); } \
+      }                                                                                                  \
+    }                                                                                                    \
+  }                                                                                                      \
+  __builtin_amdgcn_sched_barrier(0);
   for (int u = 0; u < ns; ++u) {
     // ---- even step: k-half 0 of slice u
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     PP64_READ(0)
+#if PP64_A_IN_MFMA && PP64_B_IN_MFMA
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      const bool doB = u + 1 < ns && dma_on;
+      PP64_MFMA_B()
+    }
+#else
     if (u + 1 < ns && dma_on)
       dma_tile<!TB_KMAJOR, BN>(gB, gldb, n0, kbeg + (u + 1) * 64, smem + B_OFF + ((u + 1) & 1) * B_UNIT, wave, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PP64_MFMA()
+#endif
     // ---- odd step: k-half 1 of slice u
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     PP64_READ(1)
+#if PP64_A_IN_MFMA
+    // Slice u + 1 (A_{u+1}: issued during the previous odd step's MFMAs, B_{u+1}: in this slice's even step) must have landed
+    // BEFORE the barrier below: the other wave group, one barrier ahead, starts reading it right after that barrier.  (Waiting after
+    // the MFMAs -- "all but the four pieces just issued" -- is one barrier too late for the lagging group's pieces: measured as wrong
+    // results on the forward layout.)  Nothing younger is in flight at this point, so the wait is a full drain and nearly free.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      const bool doA = u + 2 < ns && dma_on;
+      int sn = sa + 2; if (sn >= 3) sn -= 3;
+      PP64_MFMA_A()
+    }
+#else
     if (u + 2 < ns) {
       int sn = sa + 2; if (sn >= 3) sn -= 3;
       if (dma_on) dma_tile<TA, GBM>(gA, glda, m0, kbeg + (u + 2) * 64, smem + sn * A_UNIT, wave, lane);
@@ -329,8 +439,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PP64_MFMA()
+#endif
     sa = sa + 1; if (sa >= 3) sa = 0;
   }
+#undef PP64_MFMA_A
+#undef PP64_MFMA_B
+#undef PP64_MFMA_X
 #undef PP64_READ
 #undef PP64_MFMA
   if (grp == 0) __builtin_amdgcn_s_barrier();            // both groups have now executed 4 ns + 1 barriers
@@ -342,6 +456,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
       atomicAdd(dst + 16, bacc[1][0]);
     }
   }
+  // Round 3, measured and not kept: pulling the NEXT workgroup's first operand slices (the workgroup 32 further in this XCD's
+  // chunk: A slices 0 and 1, B slice 0, 96 KiB) into this XCD's L2 with register-destination loads issued between the two
+  // epilogue halves, so that the chip-wide prologue burst (MI355X_MICROARCH.md: ~9k cycles per 96 KiB with every CU in its
+  // prologue) finds its lines on-die: 1661 / 1681 us against 1675 / 1675 us over the eight forward / data-gradient products of a
+  // layer (tools/bench_gemm_epi.py, alternating builds on one box) -- no gain; the burst is not an L2-miss problem.
   const bool fs = split == 0;
   float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
   if (PP64_DBG(p) & 8) {
