@@ -30,13 +30,46 @@
 #define ATTN_BWD_MFMA_COLSUM 1   // v-bias column sums as ones x dV on the matrix cores (transposing reads of the dV image); 0: 2-byte LDS reads
 #endif
 
+// Diagnostic build only (-DATTN_STAMP=1, tools/attn_stamps.py): s_memtime stamps of wave 0 of every 64th workgroup, written to a
+// buffer of their own that nothing else reads.  The product build (ATTN_STAMP=0) contains none of this.
+#ifndef ATTN_STAMP
+#define ATTN_STAMP 0
+#endif
+// ATTN_BWD_PERSIST=1: two workgroups per CU walk the (batch, head) pairs and request the next pair's start-up loads under the current
+// pair's tail.  Measured r03 (B=256, S=128, 16 heads, one box, alternating): 163-166 us against 164-171 us with dropout and bias sums,
+// 150 against 139-142 us without the bias sums -- no gain: the second resident workgroup already covers the start-up round trip.  Off.
+#ifndef ATTN_BWD_PERSIST
+#define ATTN_BWD_PERSIST 0
+#endif
+#if ATTN_STAMP
+__device__ unsigned long long g_attn_stamps[64 * 64];
+extern "C" int mmsim_debug_attn_stamps(unsigned long long* host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * 64 * 64);
+}
+#define STAMP(i)                                                                                   \
+  do {                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    if ((blockIdx.x & 63) == 0 && threadIdx.x == 0) {                                              \
+      unsigned long long t_;                                                                       \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+      g_attn_stamps[(blockIdx.x >> 6) * 64 + (i)] = t_;                                            \
+    }                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
 struct AttnParams {
   const bf16* qkv; const int64_t* mask; bf16* ctx; const bf16* dctx; float* lse; bf16* dqkv;
   float* dbias_parts;    // backward: per-batch-element column sums of dqkv, slab [B][3H] (NULL = off)
   int ld_qkv, ld_ctx, heads, H;
   float scale;
   unsigned long long seed; const unsigned long long* seed_dev; unsigned int stream, thresh; float inv_keep;
+  int pairs;                 // B * heads (backward: persistent workgroups walk them)
 };
+
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));      // 16-byte chunk as a register vector (inline-asm operand; uint4 is a struct)
 
 __device__ __forceinline__ bf8 cvt8(const f16v& a, int s2, float mul) {
   bf8 r;
@@ -45,7 +78,9 @@ __device__ __forceinline__ bf8 cvt8(const f16v& a, int s2, float mul) {
   return r;
 }
 
-template <int NT>
+// DROP: dropout is compiled in (p.thresh != 0) -- as a template argument, not a test of the kernel argument: the wave-uniform branches
+// around every hash and keep-select cut the softmax section into ~25 basic blocks per tile that the scheduler could not merge.
+template <int NT, bool DROP>
 __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_FWD_WAVES))) void attn_fwd_kernel(AttnParams p) {
   constexpr int S = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -56,30 +91,39 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_FW
   const int bh = blockIdx.x, b = bh / p.heads, h = bh % p.heads;
   const bf16* base = p.qkv + (size_t)b * S * p.ld_qkv + h * 64;
 
-  // stage K and V rows (8 x 16-byte chunks per row)
-  {   // S*8 chunks over 64*NT threads = 4 trips: all 8 loads requested before the first LDS store
-    uint4 kv[4], vv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + i * 64 * NT, row = c >> 3, ch = c & 7;
-      kv[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * p.ld_qkv + p.H + ch * 8);
-      vv[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * p.ld_qkv + 2 * p.H + ch * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + i * 64 * NT, row = c >> 3, ch = c & 7;
-      *reinterpret_cast<uint4*>(Ks + row * ROW_PITCH + ch * 16) = kv[i];
-      *reinterpret_cast<uint4*>(Vs + row * TRV_PITCH + ch * 16) = vv[i];
-    }
-  }
-  for (int i = tid; i < S; i += 64 * NT) mb[i] = (p.mask && p.mask[(size_t)b * S + i] == 0) ? -1e30f : 0.f;
-
-  // Q^T fragments (B operand): lane = query column
+  // Start-up: K and V rows (8 x 16-byte chunks per row; S*8 chunks over 64*NT threads = 4 trips), the Q^T fragments (B operand: lane =
+  // query column), the mask row and the step's seed word are ALL requested before the first LDS store waits -- one memory round trip,
+  // in one basic block (r03: with the mask loop and the fragment loads behind the K / V stores the workgroup began with three
+  // dependent round trips).  The mask row: 64*NT = 2 S threads, the upper half handles row S-1 again (same value: no branch); without a
+  // mask the load goes to a valid dummy address and is ignored.
   const int qrow = 32 * w + (lane & 31);
   bf8 qf[4];
+  uint64_t seed_r = DROP ? step_seed(p.seed, p.seed_dev) : 0;
+  {
+    u4v kv[4], vv[4];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk)
-    qf[kk] = *reinterpret_cast<const bf8*>(base + (size_t)qrow * p.ld_qkv + 16 * kk + 8 * hh);
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 64 * NT, row = c >> 3, ch = c & 7;
+      kv[i] = *reinterpret_cast<const u4v*>(base + (size_t)row * p.ld_qkv + p.H + ch * 8);
+      vv[i] = *reinterpret_cast<const u4v*>(base + (size_t)row * p.ld_qkv + 2 * p.H + ch * 8);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      qf[kk] = *reinterpret_cast<const bf8*>(base + (size_t)qrow * p.ld_qkv + 16 * kk + 8 * hh);
+    const int mrow = tid < S ? tid : S - 1;
+    const int64_t* mptr = p.mask ? p.mask + (size_t)b * S + mrow : reinterpret_cast<const int64_t*>(p.qkv);
+    const int64_t mask_r = *mptr;
+    // every loaded value passes through ONE empty asm: all loads are issued above it and complete there together (left alone the
+    // scheduler chains load -> wait -> store through a single register quad: eight dependent round trips)
+    asm volatile("" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 64 * NT, row = c >> 3, ch = c & 7;
+      *reinterpret_cast<u4v*>(Ks + row * ROW_PITCH + ch * 16) = kv[i];
+      *reinterpret_cast<u4v*>(Vs + row * TRV_PITCH + ch * 16) = vv[i];
+    }
+    mb[mrow] = (p.mask && mask_r == 0) ? -1e30f : 0.f;
+  }
   __syncthreads();
 
   f16v sacc[NT];
@@ -117,8 +161,8 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_FW
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
   if (hh == 0 && p.lse) p.lse[(size_t)bh * S + qrow] = mx + __logf(sum);
-  if (p.thresh) {                       // accumulator registers r, r+1 (r even) are keys k, k+1: one hash per pair
-    const uint32_t dkey = drop_key(step_seed(p.seed, p.seed_dev), p.stream);
+  if (DROP) {                           // accumulator registers r, r+1 (r even) are keys k, k+1: one hash per pair
+    const uint32_t dkey = drop_key(seed_r, p.stream);
     const unsigned long long rowbase = ((unsigned long long)bh * S + qrow) * S;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
@@ -160,7 +204,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_FW
 // the loads ride under the MFMA / exp work instead of in front of it), and the dS^T image: 48 KiB at S = 128.
 // delta[q] = sum_d dO[q][d] O[q][d] comes out of the staging step (the thread that parks a 16-byte dO chunk also holds the
 // matching O chunk: an 8-lane shuffle sum per row), so dO and O are read from HBM exactly once.
-template <int NT>
+template <int NT, bool DROP>
 __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BWD_WAVES))) void attn_bwd_kernel(AttnParams p) {
   constexpr int S = 32 * NT;
   constexpr int TPW = 8 / NT;   // dQ 16x16 tiles per wave per query tile
@@ -177,18 +221,19 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
   float* cb = fl + 2 * S + 64;              // [NT][192] column sums of this (b, h)'s dq | dk | dv (bias gradient of the QKV projection),
                                             // one slot per wave: each wave adds into its own in program order, the slots are summed in wave order
                                             // (LDS float atomics from several waves arrive in varying order: last-bit run-to-run differences)
-  float cq[TPW][4];
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) cq[t][0] = cq[t][1] = cq[t][2] = cq[t][3] = 0.f;
-  if (p.dbias_parts)
-    for (int i = threadIdx.x; i < 192 * NT; i += NTHR) cb[i] = 0.f;       // ordered before the adds by the barriers of the loop
+  STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5;
-  const int bh = blockIdx.x, b = bh / p.heads, h = bh % p.heads;
-  const bf16* base = p.qkv + (size_t)b * S * p.ld_qkv + h * 64;
-  const bf16* dob = p.dctx + (size_t)b * S * p.ld_ctx + h * 64;
-  const bf16* ob = p.ctx + (size_t)b * S * p.ld_ctx + h * 64;
+  const int key = 32 * w + (lane & 31);
+  // (mask / lse rows: NTHR = 2 S threads, the upper half handles row S-1 again -- same values, no branch)
 
+  // One (batch, head) pair per workgroup; with ATTN_BWD_PERSIST the grid is two workgroups per CU, each walks the pairs bh, bh + grid,
+  // ... and requests the NEXT pair's start-up loads right after the tile loop (accumulators written out, registers free).
+  u4v kv[4];                                // K image chunks of the pair being started
   uint4 tq[CPT], to[CPT], tc[CPT];          // the tile in flight: q, dO, O chunks
+  bf8 kreg[4], vreg[4];                     // loop-invariant B operands: K^T and V^T columns for this wave's 32 keys (lane = key)
+  float lse_r;
+  int64_t mask_r;
+  const bf16 *base, *dob, *ob;              // the current pair's q rows, dO rows, O rows
   auto issue = [&](int qt) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
@@ -212,37 +257,87 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
       if (ch == 0) dlt[bf * 32 + row] = acc;
     }
   };
+  // EVERY global load of a pair's start-up is requested here, before anything waits for any of them: one memory round trip instead
+  // of three dependent ones (r03 stamps: 8.0k of 45k cycles went to the start-up when the mask / lse and operand loads were issued
+  // only after the K image had landed).  No branches: without a mask the load goes to a valid dummy address and is ignored (with
+  // branches the compiler sank loads below the first wait).
+  auto load_pair = [&](int nbh) {
+    // the thread index passes through an empty asm: the per-lane row offsets below are recomputed at every call instead of being
+    // hoisted out of the pair loop, where ~20 registers of loop-invariant addresses lived through the tile loop and spilled it
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));
+    const int key2 = 32 * (t2 >> 6) + (t2 & 31), hh2 = (t2 & 63) >> 5, mrow2 = t2 < S ? t2 : S - 1;
+    const int nb = nbh / p.heads, nh = nbh % p.heads;
+    const bf16* nbase = p.qkv + (size_t)nb * S * p.ld_qkv + nh * 64;
+    const bf16* ndob = p.dctx + (size_t)nb * S * p.ld_ctx + nh * 64;
+    const bf16* nob = p.ctx + (size_t)nb * S * p.ld_ctx + nh * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {     // K image: 4 chunks per thread
+      const int c = t2 + i * NTHR, row = c >> 3, ch = c & 7;
+      kv[i] = *reinterpret_cast<const u4v*>(nbase + (size_t)row * p.ld_qkv + p.H + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {   // tile 0
+      const int c = t2 + i * NTHR, row = c >> 3, ch = c & 7;
+      tq[i] = *reinterpret_cast<const uint4*>(nbase + (size_t)row * p.ld_qkv + ch * 8);
+      to[i] = *reinterpret_cast<const uint4*>(ndob + (size_t)row * p.ld_ctx + ch * 8);
+      tc[i] = *reinterpret_cast<const uint4*>(nob + (size_t)row * p.ld_ctx + ch * 8);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (!ATTN_BWD_KLDS) kreg[kk] = *reinterpret_cast<const bf8*>(nbase + (size_t)key2 * p.ld_qkv + p.H + 16 * kk + 8 * hh2);
+      vreg[kk] = *reinterpret_cast<const bf8*>(nbase + (size_t)key2 * p.ld_qkv + 2 * p.H + 16 * kk + 8 * hh2);
+    }
+    lse_r = p.lse[(size_t)nbh * S + mrow2];
+    const int64_t* mptr = p.mask ? p.mask + (size_t)nb * S + mrow2 : reinterpret_cast<const int64_t*>(p.qkv);
+    mask_r = *mptr;
+  };
 
-  {   // K image (4 chunks per thread) + tile 0: every load requested before the first LDS store
-    uint4 kv[4];
+  uint64_t seed_r = DROP ? step_seed(p.seed, p.seed_dev) : 0;      // the step's device seed word: requested with the rest
+  int bh = blockIdx.x;
+  load_pair(bh);
+  asm volatile("" : "+v"(seed_r));
+  const uint32_t dkey = drop_key(seed_r, p.stream);
+
+#pragma unroll 1
+  for (;;) {
+  const int b = bh / p.heads, h = bh % p.heads;
+  base = p.qkv + (size_t)b * S * p.ld_qkv + h * 64;
+  dob = p.dctx + (size_t)b * S * p.ld_ctx + h * 64;
+  ob = p.ctx + (size_t)b * S * p.ld_ctx + h * 64;
+  float cq[TPW][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) cq[t][0] = cq[t][1] = cq[t][2] = cq[t][3] = 0.f;
+  if (p.dbias_parts)
+    for (int i = threadIdx.x; i < 192 * NT; i += NTHR) cb[i] = 0.f;       // ordered before the stores into it by the barriers of the loop
+  STAMP(1);
+  // the K image passes through ONE empty asm: every load of the start-up was issued before it (see attn_fwd_kernel)
+  asm volatile("" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]));
+  {
+    int t1 = tid;                       // opaque copy, as in load_pair
+    asm volatile("" : "+v"(t1));
+    const int mrow1 = t1 < S ? t1 : S - 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int c = tid + i * NTHR, row = c >> 3, ch = c & 7;
-      kv[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * p.ld_qkv + p.H + ch * 8);
+      const int c = t1 + i * NTHR, row = c >> 3, ch = c & 7;
+      *reinterpret_cast<u4v*>(Ks + row * ROW_PITCH + ch * 16) = kv[i];
     }
-    issue(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + i * NTHR, row = c >> 3, ch = c & 7;
-      *reinterpret_cast<uint4*>(Ks + row * ROW_PITCH + ch * 16) = kv[i];
-    }
-  }
-  for (int i = tid; i < S; i += NTHR) {
-    mb[i] = (p.mask && p.mask[(size_t)b * S + i] == 0) ? -1e30f : 0.f;
-    lse[i] = p.lse[(size_t)bh * S + i];
-  }
-  // loop-invariant B operands: K^T and V^T columns for this wave's 32 keys (lane = key)
-  const int key = 32 * w + (lane & 31);
-  bf8 kreg[4], vreg[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    if (!ATTN_BWD_KLDS) kreg[kk] = *reinterpret_cast<const bf8*>(base + (size_t)key * p.ld_qkv + p.H + 16 * kk + 8 * hh);
-    vreg[kk] = *reinterpret_cast<const bf8*>(base + (size_t)key * p.ld_qkv + 2 * p.H + 16 * kk + 8 * hh);
+    mb[mrow1] = (p.mask && mask_r == 0) ? -1e30f : 0.f;
+    lse[mrow1] = lse_r;
   }
   park(0);
+  // The operand registers are USED here so that the compiler's wait for their loads sits in front of the tile loop: inside the loop
+  // body it would be a vmcnt wait that also covers the next tile's loads just issued there (in-order counter), i.e. the prefetch would
+  // be waited for at once -- r03 stamps showed exactly that: +1400 cycles in every iteration that issues a prefetch.
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    asm volatile("" : "+v"(vreg[kk]));
+    if (!ATTN_BWD_KLDS) asm volatile("" : "+v"(kreg[kk]));
+  }
+  STAMP(2);
   __syncthreads();
+  STAMP(3);
   const float mbk = mb[key];
-  const uint32_t dkey = drop_key(step_seed(p.seed, p.seed_dev), p.stream);
 
   f16v dV[2], dK[2];
 #pragma unroll
@@ -257,6 +352,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
     const char* Os = Ot + cur * TILE;
     const float* dl = dlt + cur * 32;
     char* Ds = Ds0 + (ATTN_BWD_DS2 ? cur * S * DST_PITCH : 0);
+    STAMP(4 + 8 * qt);
     if (qt + 1 < NT) issue(qt + 1);
     f16v X, dP;
 #pragma unroll
@@ -270,6 +366,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
       X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kreg[kk], X, 0, 0, 0);
       dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vreg[kk], dP, 0, 0, 0);
     }
+    STAMP(5 + 8 * qt);
     // X[r] -> P (dropped, for dV) ; dP[r] -> dS
     // Dropout mask: one hash serves the elements (q, key) and (q, key ^ 1), which sit on NEIGHBOURING LANES here (lane = key).
     // For the register pair (r, r + 1) = queries (q, q + 1) the even lane hashes q, the odd lane q + 1, and a quad-perm DPP
@@ -278,7 +375,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
       uint32_t bits0 = 0u, bits1 = 0u;
-      if (p.thresh) {                       // kernel argument: wave-uniform, EXEC stays full for the DPP move
+      if (DROP) {                           // compile time: EXEC stays full for the DPP move
         const int qm = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * hh + par;
         const unsigned long long idx = ((unsigned long long)bh * S + qm) * S + key;
         const uint32_t mine = drop_bits(dkey, idx >> 1);
@@ -292,11 +389,12 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
         const int ql = (rr & 3) + 8 * (rr >> 2) + 4 * hh, q = 32 * qt + ql;
         const float pr = __expf(X[rr] * p.scale + mbk - lse[q]);
         float ks = 1.0f;
-        if (p.thresh) ks = drop_keep16(k2 ? bits1 : bits0, par, p.thresh) ? p.inv_keep : 0.f;
+        if (DROP) ks = drop_keep16(k2 ? bits1 : bits0, par, p.thresh) ? p.inv_keep : 0.f;
         X[rr] = pr * ks;
         dP[rr] = pr * (dP[rr] * ks - dl[ql]);
       }
     }
+    STAMP(6 + 8 * qt);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -308,14 +406,18 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
         dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, pb, dV[dt], 0, 0, 0);
         dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, sb, dK[dt], 0, 0, 0);
       }
+    STAMP(7 + 8 * qt);
     // dS^T[key][q_local] (bf16) -> LDS
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       bf4 o = {f2bf(dP[4 * g4]), f2bf(dP[4 * g4 + 1]), f2bf(dP[4 * g4 + 2]), f2bf(dP[4 * g4 + 3])};
       *reinterpret_cast<bf4*>(Ds + key * DST_PITCH + (8 * g4 + 4 * hh) * 2) = o;
     }
+    STAMP(8 + 8 * qt);
     if (qt + 1 < NT) park(cur ^ 1);       // the other buffer was last read before the previous iteration's first barrier
+    STAMP(9 + 8 * qt);
     __syncthreads();
+    STAMP(10 + 8 * qt);
     // dQ[q][d] = scale * sum_key dS[q][key] K[key][d] : 8 tiles of 16x16 per query tile, TPW per wave
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -336,9 +438,11 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
     }
     // one dS^T image: the next tile's writes must wait for these reads.  Two images: the image written next was last read before
     // the barrier above of the PREVIOUS iteration, the Q / dO buffer parked next was last read before this iteration's barrier
+    STAMP(11 + 8 * qt);
     if (!ATTN_BWD_DS2) __syncthreads();
   }
   if (ATTN_BWD_DS2) __syncthreads();         // the K image and tile buffers are reused below
+  STAMP(36);
   // dK, dV leave through LDS (the K image and the Q / dO tile buffers are free after the loop's last barrier): the
   // accumulators hold 4 channels of one key per register quad -- written straight out that is 8-byte pieces of 32 different
   // cache lines per store; from the [key][64] images every row leaves as one 128-byte line, and the column sums for the k | v
@@ -357,17 +461,11 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
       *reinterpret_cast<bf4*>(dVs + key * ROW_PITCH + d * 2) = ov;
     }
   __syncthreads();
-  {
-    bf16* dkg = p.dqkv + (size_t)b * S * p.ld_qkv + p.H + h * 64;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {       // S*8 chunks of 16 bytes per tensor over 64*NT threads
-      const int c = tid + i * NTHR, row = c >> 3, ch = c & 7;
-      const uint4 kq = *reinterpret_cast<const uint4*>(dKs + row * ROW_PITCH + ch * 16);
-      const uint4 vq = *reinterpret_cast<const uint4*>(dVs + row * ROW_PITCH + ch * 16);
-      *reinterpret_cast<uint4*>(dkg + (size_t)row * p.ld_qkv + ch * 8) = kq;
-      *reinterpret_cast<uint4*>(dkg + (size_t)row * p.ld_qkv + p.H + ch * 8) = vq;
-    }
-  }
+  STAMP(37);
+  const int nxt = bh + (int)gridDim.x;
+  const bool more = ATTN_BWD_PERSIST && nxt < p.pairs;
+  if (more) load_pair(nxt);          // accumulators are out: the registers are free, the loads land under the tail
+  // bias sums first, the 48 KiB of dK | dV row stores last: nothing in the workgroup waits behind the stores
   if (p.dbias_parts && ATTN_BWD_MFMA_COLSUM) {
     // key / value bias gradients: column sums of the ROUNDED dK / dV images as (all-ones [16 x 32 keys]) x image[32 keys x 16 d] on
     // the matrix cores -- this wave's 32 keys, four 16-column blocks per image: 8 MFMAs + 16 transposing reads per wave instead of
@@ -383,12 +481,10 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
       ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag16(dKs, ROW_PITCH, 32 * w, 16 * d4, lane), ones, ak, 0, 0, 0);
       av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag16(dVs, ROW_PITCH, 32 * w, 16 * d4, lane), ones, av, 0, 0, 0);
       // operands swapped as everywhere here: acc[e] = C[m = lane & 15][n = 16 d4 + 4 (lane >> 4) + e], all rows m equal
-      if ((lane & 15) == 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          cb[192 * w + 64 + 16 * d4 + 4 * (lane >> 4) + e] += ak[e];
-          cb[192 * w + 128 + 16 * d4 + 4 * (lane >> 4) + e] += av[e];
-        }
+      if ((lane & 15) == 0) {      // this wave's slot, every column written once: plain 16-byte stores (an LDS read-modify-write per
+                                   // element cost 4.4k cycles here: 40 dependent LDS round trips at the end of every workgroup)
+        *reinterpret_cast<f4*>(cb + 192 * w + 64 + 16 * d4 + 4 * (lane >> 4)) = ak;
+        *reinterpret_cast<f4*>(cb + 192 * w + 128 + 16 * d4 + 4 * (lane >> 4)) = av;
       }
     }
   } else if (p.dbias_parts) {          // sums of the ROUNDED values: thread = (column, wave's 32 keys)
@@ -399,20 +495,28 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
       sk += bf2f(*reinterpret_cast<const bf16*>(dKs + (k0 + r) * ROW_PITCH + d * 2));
       sv += bf2f(*reinterpret_cast<const bf16*>(dVs + (k0 + r) * ROW_PITCH + d * 2));
     }
-    cb[192 * w + 64 + d] += sk;            // this wave's slot: lane d is the only writer of column d
-    cb[192 * w + 128 + d] += sv;
+    cb[192 * w + 64 + d] = sk;             // this wave's slot: lane d is the only writer of column d
+    cb[192 * w + 128 + d] = sv;
   }
   if (p.dbias_parts) {
+    // dq: rows of a 16x16 tile sit on lanes 0..15 of each 16-lane group.  A wave's tiles w*TPW + t cover column block d4 = tile & 3:
+    // with TPW >= 4 every block TPW/4 times (summed in registers first), with TPW = 2 two of the four blocks (the others stay at the
+    // zero they were initialised to) -- each column of the wave's slot is stored once, no LDS read-modify-write.
+    constexpr int REP = TPW >= 4 ? TPW / 4 : 1, NB = TPW >= 4 ? 4 : TPW;
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {       // dq: rows of a 16x16 tile sit on lanes 0..15 of each 16-lane group
+    for (int t = 0; t < NB; ++t) {
       const int d4 = (w * TPW + t) & 3;
+      f4 sq4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float sq = cq[t][e];
 #pragma unroll
+        for (int r2 = 1; r2 < REP; ++r2) sq += cq[t + 4 * r2][e];
+#pragma unroll
         for (int o2 = 1; o2 < 16; o2 <<= 1) sq += __shfl_xor(sq, o2, 64);
-        if ((lane & 15) == 0) cb[192 * w + 16 * d4 + (lane >> 4) * 4 + e] += sq;      // same lane for a repeated d4: program order
+        sq4[e] = sq;
       }
+      if ((lane & 15) == 0) *reinterpret_cast<f4*>(cb + 192 * w + 16 * d4 + (lane >> 4) * 4) = sq4;
     }
     __syncthreads();
     for (int i = tid; i < 192; i += 64 * NT) {
@@ -421,6 +525,25 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
       for (int ww = 1; ww < NT; ++ww) t += cb[192 * ww + i];
       p.dbias_parts[(size_t)b * 3 * p.H + (i >> 6) * p.H + h * 64 + (i & 63)] = t;
     }
+  }
+  STAMP(38);
+  {
+    int t3 = tid;                       // opaque copy: the row offsets below are not hoisted out of the pair loop (see load_pair)
+    asm volatile("" : "+v"(t3));
+    bf16* dkg = p.dqkv + (size_t)b * S * p.ld_qkv + p.H + h * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {       // S*8 chunks of 16 bytes per tensor over 64*NT threads
+      const int c = t3 + i * NTHR, row = c >> 3, ch = c & 7;
+      const uint4 kq = *reinterpret_cast<const uint4*>(dKs + row * ROW_PITCH + ch * 16);
+      const uint4 vq = *reinterpret_cast<const uint4*>(dVs + row * ROW_PITCH + ch * 16);
+      *reinterpret_cast<uint4*>(dkg + (size_t)row * p.ld_qkv + ch * 8) = kq;
+      *reinterpret_cast<uint4*>(dkg + (size_t)row * p.ld_qkv + p.H + ch * 8) = vq;
+    }
+  }
+  STAMP(39);
+  if (!more) break;
+  __syncthreads();                   // the LDS images (dK | dV rows, bias slots) are free for the next pair's start-up stores
+  bh = nxt;
   }
 }
 
@@ -450,9 +573,12 @@ extern "C" int mmsim_attn_fwd(const void* qkv, int ld_qkv, const long long* mask
   const size_t lds = (size_t)S * (ROW_PITCH + TRV_PITCH) + S * 4;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(B * heads), block(64 * NT);
-  if (NT == 1) hipLaunchKernelGGL((attn_fwd_kernel<1>), grid, block, lds, s, p);
-  else if (NT == 2) hipLaunchKernelGGL((attn_fwd_kernel<2>), grid, block, lds, s, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<4>), grid, block, lds, s, p);
+  const bool drop = p.thresh != 0;
+#define ATTN_FWD_LAUNCH(N, D) hipLaunchKernelGGL((attn_fwd_kernel<N, D>), grid, block, lds, s, p)
+  if (NT == 1) { if (drop) ATTN_FWD_LAUNCH(1, true); else ATTN_FWD_LAUNCH(1, false); }
+  else if (NT == 2) { if (drop) ATTN_FWD_LAUNCH(2, true); else ATTN_FWD_LAUNCH(2, false); }
+  else { if (drop) ATTN_FWD_LAUNCH(4, true); else ATTN_FWD_LAUNCH(4, false); }
+#undef ATTN_FWD_LAUNCH
   return mmsim_check_launch("attn_fwd");
 }
 
@@ -479,13 +605,25 @@ static int attn_bwd_impl(const void* qkv, int ld_qkv, const long long* mask, con
   static unsigned long long attr_done = 0;          // per device
   const int dev = mmsim_current_device();
   if (!((attr_done >> dev) & 1)) {   // S = 128 needs 48 KiB of dynamic LDS
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_bwd_lds(128));
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_bwd_lds(128));
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_bwd_lds(128));
     attr_done |= 1ull << dev;
   }
-  dim3 grid(B * heads), block(64 * NT);
-  if (NT == 1) hipLaunchKernelGGL((attn_bwd_kernel<1>), grid, block, lds, s, p);
-  else if (NT == 2) hipLaunchKernelGGL((attn_bwd_kernel<2>), grid, block, lds, s, p);
-  else hipLaunchKernelGGL((attn_bwd_kernel<4>), grid, block, lds, s, p);
+  p.pairs = B * heads;
+  static int cus[64];                                // per device
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  const int resident = 2 * cus[dev];                 // 244-ish VGPRs: two waves per SIMD, i.e. two workgroups per CU
+  dim3 grid(ATTN_BWD_PERSIST && p.pairs > resident ? resident : p.pairs), block(64 * NT);
+  const bool drop = p.thresh != 0;
+#define ATTN_BWD_LAUNCH(N, D) hipLaunchKernelGGL((attn_bwd_kernel<N, D>), grid, block, lds, s, p)
+  if (NT == 1) { if (drop) ATTN_BWD_LAUNCH(1, true); else ATTN_BWD_LAUNCH(1, false); }
+  else if (NT == 2) { if (drop) ATTN_BWD_LAUNCH(2, true); else ATTN_BWD_LAUNCH(2, false); }
+  else { if (drop) ATTN_BWD_LAUNCH(4, true); else ATTN_BWD_LAUNCH(4, false); }
+#undef ATTN_BWD_LAUNCH
   return mmsim_check_launch("attn_bwd");
 }
 
