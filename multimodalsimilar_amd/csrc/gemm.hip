@@ -29,6 +29,10 @@ __device__ __forceinline__ int tr_key(int k) { return (k & 3) | (((k >> 3) & 1) 
 // Ragged tiles are handled by clamping the ADDRESS into the operand and AND-masking the VALUE: `if (in range) v = load`
 // makes hipcc branch around each of the 8 loads of a K-step and wait vmcnt(0) after every one (the loads then complete
 // one L2 round trip after the other).
+// The mask is a SEPARATE step (mask_tile), applied where the registers are parked in LDS: applied with the load -- as it was up to
+// r03 -- the AND is a use of the loaded value inside the prefetch's own basic block, hipcc put its vmcnt waits there, IN FRONT of
+// the K-step's MFMAs, and the "prefetch" was waited for at once: every K-step of every image-tower 1x1 convolution paid a full
+// memory round trip (found in the ISA after the same pattern showed up in the attention backward's stamps).
 template <bool TRANS>
 __device__ __forceinline__ void load_tile(const bf16* __restrict__ X, int ld, int r0, int R, int k0, int kend,
                                           int tid, uint4 (&reg)[4]) {
@@ -36,21 +40,28 @@ __device__ __forceinline__ void load_tile(const bf16* __restrict__ X, int ld, in
   for (int i = 0; i < 4; ++i) {
     const int c = tid + 256 * i;
     const bf16* src;
-    bool ok;
     if (!TRANS) {
       const int row = c >> 3, kc = c & 7;
       const int gr = r0 + row, gk = k0 + kc * 8;
-      ok = gr < R && gk < kend;
       src = X + (size_t)min(gr, R - 1) * ld + (gk < kend ? gk : k0);
     } else {
       const int krow = c >> 4, rc = c & 15;
       const int gk = k0 + krow, gr = r0 + rc * 8;
-      ok = gk < kend && gr < R;
       src = X + (size_t)min(gk, kend - 1) * ld + (gr < R ? gr : r0);
     }
-    const uint4 v = *reinterpret_cast<const uint4*>(src);
+    reg[i] = *reinterpret_cast<const uint4*>(src);
+  }
+}
+template <bool TRANS>
+__device__ __forceinline__ void mask_tile(int r0, int R, int k0, int kend, int tid, uint4 (&reg)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    bool ok;
+    if (!TRANS) ok = r0 + (c >> 3) < R && k0 + (c & 7) * 8 < kend;
+    else ok = k0 + (c >> 4) < kend && r0 + (c & 15) * 8 < R;
     const unsigned int msk = ok ? 0xffffffffu : 0u;
-    reg[i] = make_uint4(v.x & msk, v.y & msk, v.z & msk, v.w & msk);
+    reg[i] = make_uint4(reg[i].x & msk, reg[i].y & msk, reg[i].z & msk, reg[i].w & msk);
   }
 }
 
@@ -200,6 +211,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, ch
   XfGate xg;
   load_tile<TA>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
   load_tile<!TB_KMAJOR>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb);
+  mask_tile<TA>(m0, p.M, kbeg, kend, tid, ra);
+  mask_tile<!TB_KMAJOR>(n0, p.N, kbeg, kend, tid, rb);
   if (XF == 1) { xform_request<TA>(p, m0, p.M, kbeg, kend, tid, xg); xform_tile<TA, FMT>(p, m0, p.M, kbeg, kend, tid, ra, xg); }
   if (XF == 2) { xform_request<!TB_KMAJOR>(p, n0, p.N, kbeg, kend, tid, xg); xform_tile<!TB_KMAJOR, FMT>(p, n0, p.N, kbeg, kend, tid, rb, xg); }
   if (FMT == 2 && XF == 0) convert_tile_f16_bf16(rb);
@@ -232,6 +245,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, ch
                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
     if (t + 1 < nk) {
+      mask_tile<TA>(m0, p.M, kbeg + (t + 1) * BK, kend, tid, ra);
+      mask_tile<!TB_KMAJOR>(n0, p.N, kbeg + (t + 1) * BK, kend, tid, rb);
       if (XF == 1) xform_tile<TA, FMT>(p, m0, p.M, kbeg + (t + 1) * BK, kend, tid, ra, xg);
       if (XF == 2) xform_tile<!TB_KMAJOR, FMT>(p, n0, p.N, kbeg + (t + 1) * BK, kend, tid, rb, xg);
       if (FMT == 2 && XF == 0) convert_tile_f16_bf16(rb);

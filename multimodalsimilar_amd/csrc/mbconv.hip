@@ -717,20 +717,37 @@ __global__ __launch_bounds__(NTHR) void pw_expand_bwd_kernel(PwBwd p) {
 #pragma unroll
   for (int i = 0; i < MAXW; ++i) dW[i] = f4{0.f, 0.f, 0.f, 0.f};
   const int nchunks = BM * G;
-  uint4 vd[NCH], vz[NCH];
+  constexpr int NX = (BM * CIN_T * 2 + NTHR - 1) / NTHR;   // 16-byte chunks of the strip's x rows per thread (cin <= 16 CIN_T)
+  constexpr int TPD = (MTD * CIN_T + NW - 1) / NW;         // dx tiles per wave
+  const int xg = p.cin >> 3, nxch = BM * xg;
+  typedef unsigned int u4v __attribute__((ext_vector_type(4)));      // 16-byte chunk as a register vector (inline-asm operand)
+  u4v vd[NCH], vz[NCH], vx[NX];
+  // the next strip's dpre | z1 | x rows: requested as a whole, consumed at the top of the next trip
   auto request = [&](int strip) {
     const size_t base = (size_t)strip * BM * p.mid;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int q = min(tid + NTHR * i, nchunks - 1);
-      vd[i] = *reinterpret_cast<const uint4*>(p.dpre + base + (size_t)q * 8);
-      vz[i] = *reinterpret_cast<const uint4*>(p.z1 + base + (size_t)q * 8);
+      vd[i] = *reinterpret_cast<const u4v*>(p.dpre + base + (size_t)q * 8);
+      vz[i] = *reinterpret_cast<const u4v*>(p.z1 + base + (size_t)q * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int q = min(tid + NTHR * i, nxch - 1);          // rows of a strip are contiguous in x: chunk q of the strip
+      vx[i] = *reinterpret_cast<const u4v*>(p.x + (size_t)strip * BM * p.cin + (size_t)q * 8);
     }
   };
   int strip = blockIdx.x;
   if (strip < p.nstrips) request(strip);
   for (; strip < p.nstrips; strip += gridDim.x) {
     __syncthreads();                     // the previous strip's MFMAs have read the images (first trip: the staging above)
+    // every prefetched chunk is USED here, whether or not this thread stages it: a chunk skipped by `q < nchunks` below is a load
+    // hipcc never saw waited for, and before its registers are written again (the next request) it then waits vmcnt(0) -- which
+    // sat between the residual loads and the request and exposed both
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(vd[i]), "+v"(vz[i]));
+#pragma unroll
+    for (int i = 0; i < NX; ++i) asm volatile("" : "+v"(vx[i]));
     // ---- dz1 -> Z image, x -> X image
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -746,12 +763,13 @@ __global__ __launch_bounds__(NTHR) void pw_expand_bwd_kernel(PwBwd p) {
         *reinterpret_cast<bf8*>(zimg + pix * ZP + un * 16) = o;
       }
     }
-    {
-      const int xg = p.cin >> 3;
-      for (int q = tid; q < BM * xg; q += NTHR) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int q = tid + NTHR * i;
+      if (q < nxch) {
         const int pix = q / xg, un = q - pix * xg;
         // x is fp16 in HBM; the weight-gradient MFMA pairs it with the bf16 dz1 image, so it is staged as bf16
-        const h8 xv = *reinterpret_cast<const h8*>(p.x + ((size_t)strip * BM + pix) * p.cin + un * 8);
+        const h8 xv = __builtin_bit_cast(h8, vx[i]);
         bf8 xo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) xo[e] = f2bf(h2f(xv[e]));
@@ -759,26 +777,43 @@ __global__ __launch_bounds__(NTHR) void pw_expand_bwd_kernel(PwBwd p) {
       }
     }
     __syncthreads();
-    if (strip + (int)gridDim.x < p.nstrips) request(strip + gridDim.x);      // the next strip's loads fly under the MFMAs
-    // ---- dx = dz1 W1: (BM/16) x CIN_T tiles over the waves
-    for (int t = wave; t < MTD * CIN_T; t += NW) {
-      const int mt = t / CIN_T, nt = t - mt * CIN_T;
-      f4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int ks = 0; ks < p.KS; ++ks) {
-        const bf8 zf = *reinterpret_cast<const bf8*>(zimg + (mt * 16 + (lane & 15)) * ZP + (ks * 4 + (lane >> 4)) * 16);
-        const bf8 wf = tr_frag16(wimg, XP, ks * 32, nt * 16, lane);
-        acc = mfma16(wf, zf, acc);
-      }
-      const int pix = mt * 16 + (lane & 15), ci = nt * 16 + (lane >> 4) * 4;
-      if (ci < p.cin) {                  // cin is a multiple of 8: a 4-channel group is valid as a whole
-        const size_t off = ((size_t)strip * BM + pix) * p.cin + ci;
-        if (p.resid) {
-          const bf4 r = *reinterpret_cast<const bf4*>(p.resid + off);
+    // The residual rows of this wave's dx tiles are requested BEFORE the next strip's loads: the memory counter is in order, so a
+    // residual load issued after them (as it was up to r03, inside the tile loop) made its wait a wait for the whole prefetch -- in
+    // front of the MFMAs it was meant to fly under.
+    bf4 rres[TPD];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] += bf2f(r[e]);
+    for (int i = 0; i < TPD; ++i) {
+      const int t = wave + NW * i, mt = t / CIN_T, nt = t - mt * CIN_T;
+      const int pix = mt * 16 + (lane & 15), ci = min(nt * 16 + (lane >> 4) * 4, p.cin - 4);
+      rres[i] = bf4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+      if (p.resid) rres[i] = *reinterpret_cast<const bf4*>(p.resid + ((size_t)strip * BM + min(pix, BM - 1)) * p.cin + ci);   // launch-uniform branch
+    }
+    // the next strip's loads fly under the MFMAs.  UNCONDITIONAL (the last trip re-requests its own strip and drops it): behind
+    // `if (next < nstrips)` the number of loads younger than the residual rows differs between the two paths, hipcc's counted wait
+    // for those rows falls back to vmcnt(0), and the prefetch is waited for after the first tile's MFMAs.
+    request(min(strip + (int)gridDim.x, p.nstrips - 1));
+    // ---- dx = dz1 W1: (BM/16) x CIN_T tiles over the waves
+#pragma unroll
+    for (int i = 0; i < TPD; ++i) {
+      const int t = wave + NW * i;
+      if (t < MTD * CIN_T) {             // wave-uniform
+        const int mt = t / CIN_T, nt = t - mt * CIN_T;
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < p.KS; ++ks) {
+          const bf8 zf = *reinterpret_cast<const bf8*>(zimg + (mt * 16 + (lane & 15)) * ZP + (ks * 4 + (lane >> 4)) * 16);
+          const bf8 wf = tr_frag16(wimg, XP, ks * 32, nt * 16, lane);
+          acc = mfma16(wf, zf, acc);
         }
-        const bf4 o = {f2bf(acc[0]), f2bf(acc[1]), f2bf(acc[2]), f2bf(acc[3])};
-        *reinterpret_cast<bf4*>(p.dx + off) = o;
+        const int pix = mt * 16 + (lane & 15), ci = nt * 16 + (lane >> 4) * 4;
+        if (ci < p.cin) {                // cin is a multiple of 8: a 4-channel group is valid as a whole
+          const size_t off = ((size_t)strip * BM + pix) * p.cin + ci;
+          asm volatile("" : "+v"(rres[i]));      // first use HERE: without it the scheduler converts the rows to fp32 ahead of the
+                                                 // prefetch above and the wait for them moves in front of it
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += bf2f(rres[i][e]);
+          const bf4 o = {f2bf(acc[0]), f2bf(acc[1]), f2bf(acc[2]), f2bf(acc[3])};
+          *reinterpret_cast<bf4*>(p.dx + off) = o;
+        }
       }
     }
     // ---- dW1 += dz1^T x: tiles (mid/16) x CIN_T, reduction over the strip's pixels
