@@ -722,7 +722,9 @@ __global__ __launch_bounds__(NTHR) void pw_expand_bwd_kernel(PwBwd p) {
   const int xg = p.cin >> 3, nxch = BM * xg;
   typedef unsigned int u4v __attribute__((ext_vector_type(4)));      // 16-byte chunk as a register vector (inline-asm operand)
   u4v vd[NCH], vz[NCH], vx[NX];
-  // the next strip's dpre | z1 | x rows: requested as a whole, consumed at the top of the next trip
+  // the next strip's dpre | z1 | x rows: requested as a whole, consumed at the top of the next trip.  (Round 3: a second register set
+  // with the loads issued TWO trips ahead measured 2-4 % slower than this form, 226-229 vs 220-223 us at 56^2 x 192 -- three of these
+  // workgroups share a CU, the round trip is already covered; tools/bench_pwexpbwd.py.)
   auto request = [&](int strip) {
     const size_t base = (size_t)strip * BM * p.mid;
 #pragma unroll

@@ -22,4 +22,7 @@ for name, hw, cin, mid in (("1.x 56^2", 3136, 32, 192), ("2.x 28^2", 784, 56, 33
     tt = t(lambda: lib.pw_expand_bwd(dpre.data_ptr(), z1.data_ptr(), x.data_ptr(), None, w1.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(),
                                      sums.data_ptr(), dx.data_ptr(), dw.data_ptr(), dg.data_ptr(), db.data_ptr(), P, mid, cin, scr.data_ptr(), scr.numel(), s))
     by = (2 * P * mid + 2 * P * cin) * 2
-    print(f"{name} cin={cin} mid={mid}: {tt:6.0f} us {by/tt/1e6:5.2f} TB/s", flush=True)
+    res = torch.randn(P, cin, device="cuda").to(bf)
+    tr = t(lambda: lib.pw_expand_bwd(dpre.data_ptr(), z1.data_ptr(), x.data_ptr(), res.data_ptr(), w1.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(),
+                                     sums.data_ptr(), dx.data_ptr(), dw.data_ptr(), dg.data_ptr(), db.data_ptr(), P, mid, cin, scr.data_ptr(), scr.numel(), s))
+    print(f"{name} cin={cin} mid={mid}: {tt:6.0f} us {by/tt/1e6:5.2f} TB/s | with residual rows {tr:6.0f} us {(by + P * cin * 2)/tr/1e6:5.2f} TB/s", flush=True)
