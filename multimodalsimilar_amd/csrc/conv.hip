@@ -519,28 +519,54 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const f16* __restrict_
     const int rbeg = blockIdx.z * rows_per_z, rend = min(HW, rbeg + rows_per_z);
     const f16* zb = z + (size_t)b * HW * C + m.cg * 8;
     const bf16* db = dy + (size_t)b * HW * C + m.cg * 8;
-    for (int r = rbeg + m.rl; r < rend; r += 4 * m.nr) {
-      uint4 zr[4], dr[4];
+    // Two row groups in flight (register sets A, B; the loop is unrolled by two): the next group's eight loads are requested before
+    // the current group's arithmetic (~200 VALU instructions per row) instead of after it.  Loads are unmasked and unconditional --
+    // rows past the end re-read the last row, their dy is zeroed where it is used -- so that every wait hipcc places is a counted one
+    // in front of the arithmetic that needs it (an AND with the load, or a load behind `if`, puts a full wait next to the load).
+    const int step = 4 * m.nr;
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));      // 16-byte chunk as a register vector (inline-asm operand)
+    auto load = [&](int r, u4v (&zr)[4], u4v (&dr)[4]) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int rq = r + q * m.nr;
-        const size_t off = (size_t)min(rq, rend - 1) * C;
-        zr[q] = ld16_masked(zb + off, rq < rend);
-        dr[q] = ld16_masked(db + off, rq < rend);
+        const size_t off = (size_t)min(r + q * m.nr, rend - 1) * C;
+        zr[q] = *reinterpret_cast<const u4v*>(zb + off);
+        dr[q] = *reinterpret_cast<const u4v*>(db + off);
       }
+    };
+    auto comp = [&](int r, u4v (&zr)[4], u4v (&dr)[4]) __attribute__((always_inline)) {
+      // first use of the set: without it the scheduler lifts this group's fp16 -> fp32 conversions into the previous group's
+      // arithmetic, and the waits for its loads with them
+#pragma unroll
+      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(zr[q]), "+v"(dr[q]));
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float ok = (r + q * m.nr < rend) ? 1.f : 0.f;     // a' of a masked (zero) z is not zero
+        const float ok = (r + q * m.nr < rend) ? 1.f : 0.f;     // a' of a row past the end is not zero
         float f[8], d[8];
-        unpack8h(zr[q], f); unpack8(dr[q], d);
+        unpack8h(__builtin_bit_cast(uint4, zr[q]), f); unpack8(__builtin_bit_cast(uint4, dr[q]), d);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float u = f[e] * sc[e] + sh[e], sg = sigmoid_f(u);
+          const float dd = d[e] * ok;
           const float a = u * sg, da = sg * (1.0f + u * (1.0f - sg)) * ok, zh = (f[e] - mu[e]) * rs[e];
-          acc[0][e] += a * d[e];
-          acc[1][e] += d[e] * da; acc[2][e] += da;
-          acc[3][e] += d[e] * da * zh; acc[4][e] += da * zh;
+          acc[0][e] += a * dd;
+          acc[1][e] += dd * da; acc[2][e] += da;
+          acc[3][e] += dd * da * zh; acc[4][e] += da * zh;
         }
+      }
+    };
+    int r = rbeg + m.rl;
+    if (r < rend) {
+      u4v zA[4], dA[4], zB[4], dB[4];
+      load(r, zA, dA);
+      for (;;) {
+        load(r + step, zB, dB);
+        comp(r, zA, dA);
+        r += step;
+        if (r >= rend) break;
+        load(r + step, zA, dA);
+        comp(r, zB, dB);
+        r += step;
+        if (r >= rend) break;
       }
     }
   }
