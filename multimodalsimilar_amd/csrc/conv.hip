@@ -101,6 +101,12 @@ __device__ __forceinline__ uint4 ld16_masked(const void* p, bool ok) {
   return make_uint4(v.x & msk, v.y & msk, v.z & msk, v.w & msk);
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+// 16-byte chunk as a register vector: what the two-groups-in-flight row loops below hold their prefetched rows in (a uint4 is a
+// struct and cannot be an inline-asm register operand).  PIPE_FIRST_USE ties a group's first use to the top of its arithmetic:
+// without it the scheduler lifts the group's conversions into the previous group's arithmetic, and the waits for its loads with them.
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+#define PIPE_FIRST_USE(a, b) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) asm volatile("" : "+v"((a)[q_]), "+v"((b)[q_]))
+__device__ __forceinline__ uint4 as_u4(u4v v) { return __builtin_bit_cast(uint4, v); }
 __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
   f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
@@ -295,6 +301,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const f16* z, const float
 }
 
 // out[b,c] = mul * sum_hw act(scale*z+shift)[b,hw,c] * (other ? other[b,hw,c] : 1)      (fp32 [B,C])
+template <bool OTHER>      // OTHER: `other` is given (compile time, so that the row loop's loads carry no branch)
 __global__ __launch_bounds__(256) void pool_bn_act_kernel(const f16* __restrict__ z, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const bf16* __restrict__ other,
                                                           float* out, int HW, int C, int act, float mul, int rows_per_z,
@@ -312,35 +319,53 @@ __global__ __launch_bounds__(256) void pool_bn_act_kernel(const f16* __restrict_
     const int rbeg = blockIdx.z * rows_per_z, rend = min(HW, rbeg + rows_per_z);
     // four rows per trip, all (bounds-masked) loads requested before the first use
     const f16* zb = z + (size_t)b * HW * C + m.cg * 8;
-    const bf16* ob = other ? other + (size_t)b * HW * C + m.cg * 8 : nullptr;      // a gradient tensor (bf16)
-    for (int r = rbeg + m.rl; r < rend; r += 4 * m.nr) {
-      uint4 zr[4], orr[4];
-      bool ok[4];
+    const bf16* ob = OTHER ? other + (size_t)b * HW * C + m.cg * 8 : nullptr;      // a gradient tensor (bf16)
+    // two row groups in flight, as in pool_bn_bwd_kernel (loads unmasked and unconditional)
+    const int step = 4 * m.nr;
+    auto load = [&](int r, u4v (&zr)[4], u4v (&orr)[4]) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int rq = r + q * m.nr;
-        ok[q] = rq < rend;
-        const size_t off = (size_t)min(rq, rend - 1) * C;
-        zr[q] = ld16_masked(zb + off, ok[q]);
-        if (ob) orr[q] = ld16_masked(ob + off, ok[q]);
+        const size_t off = (size_t)min(r + q * m.nr, rend - 1) * C;
+        zr[q] = *reinterpret_cast<const u4v*>(zb + off);
+        if (OTHER) orr[q] = *reinterpret_cast<const u4v*>(ob + off);
+        else orr[q] = zr[q];
       }
+    };
+    auto comp = [&](int r, u4v (&zr)[4], u4v (&orr)[4]) __attribute__((always_inline)) {
+      PIPE_FIRST_USE(zr, orr);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+        const bool ok = r + q * m.nr < rend;
         float f[8];
-        unpack8h(zr[q], f);
-        if (ob) {
+        unpack8h(as_u4(zr[q]), f);
+        if (OTHER) {
           float o[8];
-          unpack8(orr[q], o);            // zero for rows past the end: they add nothing
+          unpack8(as_u4(orr[q]), o);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { float y = f[e] * sc[e] + sh[e]; if (act) y = silu_f(y); acc[e] += y * o[e]; }
+          for (int e = 0; e < 8; ++e) { float y = f[e] * sc[e] + sh[e]; if (act) y = silu_f(y); acc[e] += ok ? y * o[e] : 0.f; }
         } else {
           float y8[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { float y = f[e] * sc[e] + sh[e]; if (act) y = silu_f(y); y8[e] = y; acc[e] += ok[q] ? y : 0.f; }
+          for (int e = 0; e < 8; ++e) { float y = f[e] * sc[e] + sh[e]; if (act) y = silu_f(y); y8[e] = y; acc[e] += ok ? y : 0.f; }
           // the activated tensor kept for the projection conv (its operand is then a2 * gate: one multiply per element in
           // the GEMM's staging instead of BN + SiLU + gate, which made those products VALU-bound)
-          if (act_out && ok[q]) *reinterpret_cast<uint4*>(act_out + ((size_t)b * HW + r + q * m.nr) * C + m.cg * 8) = pack8h(y8);
+          if (act_out && ok) *reinterpret_cast<uint4*>(act_out + ((size_t)b * HW + r + q * m.nr) * C + m.cg * 8) = pack8h(y8);
         }
+      }
+    };
+    int r = rbeg + m.rl;
+    if (r < rend) {
+      u4v zA[4], oA[4], zB[4], oB[4];
+      load(r, zA, oA);
+      for (;;) {
+        load(r + step, zB, oB);
+        comp(r, zA, oA);
+        r += step;
+        if (r >= rend) break;
+        load(r + step, zA, oA);
+        comp(r, zB, oB);
+        r += step;
+        if (r >= rend) break;
       }
     }
   }
@@ -524,7 +549,6 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const f16* __restrict_
     // rows past the end re-read the last row, their dy is zeroed where it is used -- so that every wait hipcc places is a counted one
     // in front of the arithmetic that needs it (an AND with the load, or a load behind `if`, puts a full wait next to the load).
     const int step = 4 * m.nr;
-    typedef unsigned int u4v __attribute__((ext_vector_type(4)));      // 16-byte chunk as a register vector (inline-asm operand)
     auto load = [&](int r, u4v (&zr)[4], u4v (&dr)[4]) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -534,15 +558,12 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const f16* __restrict_
       }
     };
     auto comp = [&](int r, u4v (&zr)[4], u4v (&dr)[4]) __attribute__((always_inline)) {
-      // first use of the set: without it the scheduler lifts this group's fp16 -> fp32 conversions into the previous group's
-      // arithmetic, and the waits for its loads with them
-#pragma unroll
-      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(zr[q]), "+v"(dr[q]));
+      PIPE_FIRST_USE(zr, dr);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float ok = (r + q * m.nr < rend) ? 1.f : 0.f;     // a' of a row past the end is not zero
         float f[8], d[8];
-        unpack8h(__builtin_bit_cast(uint4, zr[q]), f); unpack8(__builtin_bit_cast(uint4, dr[q]), d);
+        unpack8h(as_u4(zr[q]), f); unpack8(as_u4(dr[q]), d);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float u = f[e] * sc[e] + sh[e], sg = sigmoid_f(u);
@@ -662,22 +683,41 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwd p, float* part
     BnBwdCh ch;
     bn_bwd_ch(p, c0, ch);
     const int r0 = blockIdx.x * rows_per_block, r1 = min(p.P, r0 + rows_per_block);
-    for (int r = r0 + m.rl; r < r1; r += 4 * m.nr) {
-      uint4 dv[4], zv[4];
+    // two row groups in flight, as in pool_bn_bwd_kernel
+    const int step = 4 * m.nr;
+    auto load = [&](int r, u4v (&dv)[4], u4v (&zv)[4]) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const size_t off = (size_t)min(r + q * m.nr, r1 - 1) * p.C + c0;
-        dv[q] = *reinterpret_cast<const uint4*>(p.dy + off);
-        zv[q] = *reinterpret_cast<const uint4*>(p.z + off);
+        dv[q] = *reinterpret_cast<const u4v*>(p.dy + off);
+        zv[q] = *reinterpret_cast<const u4v*>(p.z + off);
       }
+    };
+    auto comp = [&](int r, u4v (&dv)[4], u4v (&zv)[4]) __attribute__((always_inline)) {
+      PIPE_FIRST_USE(dv, zv);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int rq = r + q * m.nr;
         const float ok = rq < r1 ? 1.f : 0.f;
         float da[8], zh[8];
-        bn_bwd_elem(p, ch, min(rq, r1 - 1), c0, dv[q], zv[q], da, zh);
+        bn_bwd_elem(p, ch, min(rq, r1 - 1), c0, as_u4(dv[q]), as_u4(zv[q]), da, zh);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float v = da[e] * ok; acc[e] += v; acc[8 + e] += v * zh[e]; }
+      }
+    };
+    int r = r0 + m.rl;
+    if (r < r1) {
+      u4v dA[4], zA[4], dB[4], zB[4];
+      load(r, dA, zA);
+      for (;;) {
+        load(r + step, dB, zB);
+        comp(r, dA, zA);
+        r += step;
+        if (r >= r1) break;
+        load(r + step, dA, zA);
+        comp(r, dB, zB);
+        r += step;
+        if (r >= r1) break;
       }
     }
   }
@@ -701,24 +741,43 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwd p, const float*
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] *= invP; s2[e] *= invP; }
   const int r0 = blockIdx.x * rows_per_block, r1 = min(p.P, r0 + rows_per_block);
-  for (int r = r0 + m.rl; r < r1; r += 4 * m.nr) {
-    uint4 dv[4], zv[4];
+  // two row groups in flight, as in pool_bn_bwd_kernel
+  const int step = 4 * m.nr;
+  auto load = [&](int r, u4v (&dv)[4], u4v (&zv)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const size_t off = (size_t)min(r + q * m.nr, r1 - 1) * p.C + c0;
-      dv[q] = *reinterpret_cast<const uint4*>(p.dy + off);
-      zv[q] = *reinterpret_cast<const uint4*>(p.z + off);
+      dv[q] = *reinterpret_cast<const u4v*>(p.dy + off);
+      zv[q] = *reinterpret_cast<const u4v*>(p.z + off);
     }
+  };
+  auto comp = [&](int r, u4v (&dv)[4], u4v (&zv)[4]) __attribute__((always_inline)) {
+    PIPE_FIRST_USE(dv, zv);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int rq = r + q * m.nr;
       if (rq < r1) {
         float da[8], zh[8], o[8];
-        bn_bwd_elem(p, ch, rq, c0, dv[q], zv[q], da, zh);
+        bn_bwd_elem(p, ch, rq, c0, as_u4(dv[q]), as_u4(zv[q]), da, zh);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = sc[e] * (da[e] - s1[e] - zh[e] * s2[e]);
         *reinterpret_cast<uint4*>(dz + (size_t)rq * p.C + c0) = pack8(o);
       }
+    }
+  };
+  int r = r0 + m.rl;
+  if (r < r1) {
+    u4v dA[4], zA[4], dB[4], zB[4];
+    load(r, dA, zA);
+    for (;;) {
+      load(r + step, dB, zB);
+      comp(r, dA, zA);
+      r += step;
+      if (r >= r1) break;
+      load(r + step, dA, zA);
+      comp(r, dB, zB);
+      r += step;
+      if (r >= r1) break;
     }
   }
 }
@@ -1404,8 +1463,10 @@ static int pool_bn_act_impl(const void* z, const float* scale, const float* shif
   while (!mmsim_deterministic() && nz < 16 && HW / (nz * 2 * nr) >= 16 && B * gy * nz < 2048) nz *= 2;      // >= 16 rows per row lane and z-slice: a slice costs 8 C atomics
   const int rpz = (HW + nz - 1) / nz;
   if (nz > 1) (void)hipMemsetAsync(out, 0, (size_t)B * C * sizeof(float), (hipStream_t)stream);
-  hipLaunchKernelGGL(pool_bn_act_kernel, dim3(B, gy, nz), dim3(256), 0, (hipStream_t)stream, (const f16*)z, scale, shift,
-                     (const bf16*)other, out, HW, C, act_silu, mul, rpz, (f16*)act_out);
+  if (other) hipLaunchKernelGGL(pool_bn_act_kernel<true>, dim3(B, gy, nz), dim3(256), 0, (hipStream_t)stream, (const f16*)z, scale, shift,
+                                (const bf16*)other, out, HW, C, act_silu, mul, rpz, (f16*)act_out);
+  else hipLaunchKernelGGL(pool_bn_act_kernel<false>, dim3(B, gy, nz), dim3(256), 0, (hipStream_t)stream, (const f16*)z, scale, shift,
+                          (const bf16*)nullptr, out, HW, C, act_silu, mul, rpz, (f16*)act_out);
   return mmsim_check_launch("pool_bn_act");
 }
 
