@@ -456,6 +456,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
       atomicAdd(dst + 16, bacc[1][0]);
     }
   }
+  // Round 3, measured and not kept: de-phasing the CUs (the odd half of the first round of workgroups waits 25 / 50 / 100 % of a tile's
+  // main-loop time before its prologue, so that one half's epilogue write burst meets the other half's main loop): 2.35-2.36 against
+  // 2.32-2.33 ms per layer of GEMMs (tools/bench_gemm.py) -- slightly slower; the lockstep of the rounds is not what the epilogue costs.
   // Round 3, measured and not kept: pulling the NEXT workgroup's first operand slices (the workgroup 32 further in this XCD's
   // chunk: A slices 0 and 1, B slice 0, 96 KiB) into this XCD's L2 with register-destination loads issued between the two
   // epilogue halves, so that the chip-wide prologue burst (MI355X_MICROARCH.md: ~9k cycles per 96 KiB with every CU in its
