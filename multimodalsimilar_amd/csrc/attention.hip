@@ -69,7 +69,6 @@ struct AttnParams {
   int pairs;                 // B * heads (backward: persistent workgroups walk them)
 };
 
-typedef unsigned int u4v __attribute__((ext_vector_type(4)));      // 16-byte chunk as a register vector (inline-asm operand; uint4 is a struct)
 
 __device__ __forceinline__ bf8 cvt8(const f16v& a, int s2, float mul) {
   bf8 r;

@@ -15,6 +15,15 @@ typedef __attribute__((ext_vector_type(16))) float f16v;
 // (north_star: 1e-2), fp16 by 0.6 % (oracle/effnet_ref.py emulate="fp16").  Gradients stay bf16 (range: per-element
 // gradients of a 112x112 map sit below fp16's normal range).
 typedef _Float16 f16;
+// 16-byte chunk as a REGISTER vector: what prefetching row / strip loops hold their in-flight data in (a uint4 is a struct and cannot be
+// an inline-asm register operand).  PIPE_FIRST_USE ties the first use of a prefetched group of N chunk pairs to the top of the code
+// that consumes it: without it the scheduler lifts the group's conversions above the previous group's arithmetic and the vmcnt
+// waits for its loads go with them ("Where hipcc puts s_waitcnt vmcnt").
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+#define PIPE_FIRST_USE_N(a, b, N) _Pragma("unroll") for (int q_ = 0; q_ < (N); ++q_) asm volatile("" : "+v"((a)[q_]), "+v"((b)[q_]))
+#define PIPE_FIRST_USE(a, b) PIPE_FIRST_USE_N(a, b, 4)
+#define PIPE_FIRST_USE1_N(a, N) _Pragma("unroll") for (int q_ = 0; q_ < (N); ++q_) asm volatile("" : "+v"((a)[q_]))
+__device__ __forceinline__ uint4 as_u4(u4v v) { return __builtin_bit_cast(uint4, v); }
 typedef __attribute__((ext_vector_type(8))) _Float16 h8;
 typedef __attribute__((ext_vector_type(4))) _Float16 h4;
 typedef __attribute__((ext_vector_type(2))) _Float16 h2;

@@ -101,12 +101,7 @@ __device__ __forceinline__ uint4 ld16_masked(const void* p, bool ok) {
   return make_uint4(v.x & msk, v.y & msk, v.z & msk, v.w & msk);
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
-// 16-byte chunk as a register vector: what the two-groups-in-flight row loops below hold their prefetched rows in (a uint4 is a
-// struct and cannot be an inline-asm register operand).  PIPE_FIRST_USE ties a group's first use to the top of its arithmetic:
-// without it the scheduler lifts the group's conversions into the previous group's arithmetic, and the waits for its loads with them.
-typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-#define PIPE_FIRST_USE(a, b) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) asm volatile("" : "+v"((a)[q_]), "+v"((b)[q_]))
-__device__ __forceinline__ uint4 as_u4(u4v v) { return __builtin_bit_cast(uint4, v); }
+// (u4v, PIPE_FIRST_USE, as_u4: common.h)
 __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
   f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;

@@ -264,6 +264,12 @@ struct DwBwd {
   int RG;            // row groups of the weight-gradient phase: 256 / (OG * K)
 };
 
+// Round 3, measured and not kept (tools/bench_dwt.py, alternating builds on one box; SQ counters of this kernel, tools/pmc_dwt.sh:
+// 31-41 % of a wave's cycles issue VALU instructions, 32-52 % are SQ_WAIT_ANY): the stage phase with two pixel groups in flight and raw
+// (unmasked) loads, and the data phase's z1 rows requested before the tap loop with their first use tied behind it -- 6.72 against
+// 6.70-6.79 ms over the stride-1 blocks' backward, 3 x 3 forms slightly slower, 5 x 5 slightly faster, the 5 x 5 form with the expand
+// BatchNorm's backward spills (it sits at 256 registers).  The waits of this kernel are its three barriers per tile with unevenly
+// loaded phases, not exposed load latency.
 // PLAIN = the depthwise conv's input was the block input itself (DS block of stage 0): a1 = x read as is, no BN + SiLU
 // backward on the data gradient, optional residual gradient added.
 // Per tile three phases, each with its own thread mapping and only the registers it needs:
@@ -720,7 +726,6 @@ __global__ __launch_bounds__(NTHR) void pw_expand_bwd_kernel(PwBwd p) {
   constexpr int NX = (BM * CIN_T * 2 + NTHR - 1) / NTHR;   // 16-byte chunks of the strip's x rows per thread (cin <= 16 CIN_T)
   constexpr int TPD = (MTD * CIN_T + NW - 1) / NW;         // dx tiles per wave
   const int xg = p.cin >> 3, nxch = BM * xg;
-  typedef unsigned int u4v __attribute__((ext_vector_type(4)));      // 16-byte chunk as a register vector (inline-asm operand)
   u4v vd[NCH], vz[NCH], vx[NX];
   // the next strip's dpre | z1 | x rows: requested as a whole, consumed at the top of the next trip.  (Round 3: a second register set
   // with the loads issued TWO trips ahead measured 2-4 % slower than this form, 226-229 vs 220-223 us at 56^2 x 192 -- three of these
