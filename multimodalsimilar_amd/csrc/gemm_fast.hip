@@ -456,6 +456,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
       atomicAdd(dst + 16, bacc[1][0]);
     }
   }
+  // Round 3, measured and not kept: a PERSISTENT form (one workgroup per CU walks its CU's tiles; the next tile's first slices are
+  // requested by LDS-DMA right after the main loop and land under the epilogue, which then has to work through small staging tiles in
+  // the ring slots the prefetch leaves alone).  (a) A0 | B0 | A1 ahead, fp32 16-row slices through A slot 2 / B slot 1: forward
+  // layout +3 / +2 / +4 % at K = 1024 (qkv 1 075-1 093 -> 1 108-1 124, o 1 103 -> 1 127, ffn1 1 180 -> 1 226 TFLOP/s), -3 % at K = 4096,
+  // data-gradient layout +-2 %, the layer's eight products together 2.264 against 2.258-2.264 ms: the next tile's B1 is issued after
+  // this tile's output stores, gfx9 has one in-order memory counter, so the first step's wait for B1 is a wait for the stores'
+  // acknowledgements.  (b) B1 ahead as well (128 KiB; one slot left, so the epilogue does bias / GELU in the accumulator layout and
+  // transposes bf16 slices): 256 registers, spills in the data-gradient form, -3 ... -16 %.  What persistence can hide is the
+  // prologue's latency, not its sixteen 100-cycle DMA issues per wave; tools/bench_gemm.py, MMSIM_GEMM_PERSIST builds of this round.
   // Round 3, measured and not kept: de-phasing the CUs (the odd half of the first round of workgroups waits 25 / 50 / 100 % of a tile's
   // main-loop time before its prologue, so that one half's epilogue write burst meets the other half's main loop): 2.35-2.36 against
   // 2.32-2.33 ms per layer of GEMMs (tools/bench_gemm.py) -- slightly slower; the lockstep of the rounds is not what the epilogue costs.
