@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
       float acc = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc += bf2f(a[j]) * bf2f(o[j]);
-      acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);   // the 8 chunks of a row
+      acc = sum8_dpp(acc);                 // the 8 chunks of a row: DPP moves, not three dependent ds_bpermute round trips
       if (ch == 0) dlt[bf * 32 + row] = acc;
     }
   };
@@ -511,9 +511,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_BW
         float sq = cq[t][e];
 #pragma unroll
         for (int r2 = 1; r2 < REP; ++r2) sq += cq[t + 4 * r2][e];
-#pragma unroll
-        for (int o2 = 1; o2 < 16; o2 <<= 1) sq += __shfl_xor(sq, o2, 64);
-        sq4[e] = sq;
+        sq4[e] = sum16_dpp(sq);
       }
       if ((lane & 15) == 0) *reinterpret_cast<f4*>(cb + 192 * w + 16 * d4 + (lane >> 4) * 4) = sq4;
     }

@@ -71,14 +71,40 @@ __device__ __forceinline__ float h2f(f16 x) { return (float)x; }
 // round-to-nearest-even, saturating at +-65504 (a conv output beyond fp16's range must not become inf -> NaN downstream)
 __device__ __forceinline__ f16 f2h(float x) { return (f16)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Lane exchanges inside a 16-lane row as DPP moves (VALU rate) instead of ds_bpermute round trips through the LDS crossbar (~120 cycles
+// each, and dependent in a reduction tree): quad_perm [1,0,3,2] and [2,3,0,1] for the partners 1 and 2 apart; after those every lane
+// of a quad holds the quad's total, so the MIRRORED lane of the 8-lane half-row (row_half_mirror) / of the 16-lane row (row_mirror)
+// supplies the other quad's / the other half's total.  EXEC must be full.  Partners 16 and 32 apart still go through __shfl_xor.
+template <int CTRL> __device__ __forceinline__ float dpp_mov_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sum8_dpp(float v) {       // every lane of an aligned 8-lane group ends with the group's sum
+  v += dpp_mov_f<0xB1>(v); v += dpp_mov_f<0x4E>(v); v += dpp_mov_f<0x141>(v);
   return v;
 }
+__device__ __forceinline__ float sum16_dpp(float v) {      // the same for an aligned 16-lane row
+  v = sum8_dpp(v); v += dpp_mov_f<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = sum16_dpp(v);
+  v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+  return v;
+}
+// two / four independent sums: the two remaining LDS-crossbar steps of each ride together (one latency chain, not two / four)
+__device__ __forceinline__ void wave_sum2(float& a, float& b) {
+  a = sum16_dpp(a); b = sum16_dpp(b);
+  a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+  a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+}
+__device__ __forceinline__ void wave_sum4(float& a, float& b, float& c, float& d) {
+  a = sum16_dpp(a); b = sum16_dpp(b); c = sum16_dpp(c); d = sum16_dpp(d);
+  a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64); c += __shfl_xor(c, 16, 64); d += __shfl_xor(d, 16, 64);
+  a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64); c += __shfl_xor(c, 32, 64); d += __shfl_xor(d, 32, 64);
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, dpp_mov_f<0xB1>(v)); v = fmaxf(v, dpp_mov_f<0x4E>(v)); v = fmaxf(v, dpp_mov_f<0x141>(v)); v = fmaxf(v, dpp_mov_f<0x140>(v));
+  v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
 

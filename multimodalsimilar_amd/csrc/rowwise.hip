@@ -303,8 +303,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd8_kernel(const bf16* __restrict
       }
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { s[0] += __shfl_xor(s[0], o, 64); s[1] += __shfl_xor(s[1], o, 64); }
+  wave_sum2(s[0], s[1]);
   const float mean[2] = {s[0] / H, s[1] / H};
   float qq[2] = {0.f, 0.f};
 #pragma unroll
@@ -317,8 +316,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd8_kernel(const bf16* __restrict
         for (int e = 0; e < 8; ++e) { const float d = v[q][c][e] - mean[q]; qq[q] += d * d; }
       }
     }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { qq[0] += __shfl_xor(qq[0], o, 64); qq[1] += __shfl_xor(qq[1], o, 64); }
+  wave_sum2(qq[0], qq[1]);
   const float rstd[2] = {rsqrtf(qq[0] / H + eps), rsqrtf(qq[1] / H + eps)};
   if (lane == 0) {
     mean_o[row0] = mean[0]; rstd_o[row0] = rstd[0];
@@ -509,11 +507,7 @@ __global__ __launch_bounds__(256) void ln_bwd8_kernel(const bf16* __restrict__ d
         }
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {       // the four row sums reduce together: one shuffle latency chain, not four
-      s1[0] += __shfl_xor(s1[0], o, 64); s2[0] += __shfl_xor(s2[0], o, 64);
-      s1[1] += __shfl_xor(s1[1], o, 64); s2[1] += __shfl_xor(s2[1], o, 64);
-    }
+    wave_sum4(s1[0], s2[0], s1[1], s2[1]);       // the four row sums reduce together: one shuffle latency chain, not four
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       if (q == 1 && !two) break;
