@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd8_kernel(const bf16* __restrict
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int col = lane * 8 + c * 512;
-      if (col < H) {
+      if (col < H) {      // (the branch-free form that pays in ln_bwd8_kernel's row LOOP measured 1-2 % slower in this loop-free kernel)
         tv[q][c] = __builtin_nontemporal_load(reinterpret_cast<const bf8*>(t + base + col));      // the dense output: read once
         rv[q][c] = *reinterpret_cast<const bf8*>(resid + base + col);
       }
@@ -450,7 +450,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dh_a, const bf1
 // above is latency-bound (each row is load -> two wave reductions -> store, 8 bytes per lane per stream in flight).
 // (Round 3: a one-row, next-row-prefetched form at three waves per SIMD -- 162 VGPRs instead of 236 -- measured the same 72-74 us on
 // [32768, 1024] with dropout, tools/bench_ln.py; not kept.)
-template <int NC>      // NC = ceil(H / 512)
+// Loads and arithmetic of the row loop carry NO per-lane branch (r03): lanes past H read column 0 and have their gradient zeroed, the
+// second gradient input is a template argument.  Behind `if (col < H)` / `if (dh_b)` hipcc could not pair a load with its use across
+// the two branches, assumed loads still pending at the loop's back edge and opened every trip with s_waitcnt vmcnt(0) -- a wait for
+// the previous trip's STORES to be acknowledged.
+template <int NC, bool HASB>      // NC = ceil(H / 512); HASB: dh_b is given
 __global__ __launch_bounds__(256) void ln_bwd8_kernel(const bf16* __restrict__ dh_a, const bf16* __restrict__ dh_b, const bf16* __restrict__ y,
                                                       const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                       const float* __restrict__ gamma, bf16* __restrict__ dy, bf16* __restrict__ dt,
@@ -474,12 +478,10 @@ __global__ __launch_bounds__(256) void ln_bwd8_kernel(const bf16* __restrict__ d
       const size_t base = (size_t)(row + (q && two ? 1 : 0)) * H;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const int col = lane * 8 + c * 512;
-        if (col < H) {
-          dv[q][c] = *reinterpret_cast<const bf8*>(dh_a + base + col);
-          if (dh_b) ev[q][c] = *reinterpret_cast<const bf8*>(dh_b + base + col);
-          yv[q][c] = *reinterpret_cast<const bf8*>(y + base + col);
-        }
+        const int col = lane * 8 + c * 512, colc = col < H ? col : 0;
+        dv[q][c] = *reinterpret_cast<const bf8*>(dh_a + base + colc);
+        if (HASB) ev[q][c] = *reinterpret_cast<const bf8*>(dh_b + base + colc);
+        yv[q][c] = *reinterpret_cast<const bf8*>(y + base + colc);
       }
     }
 #pragma unroll
@@ -491,19 +493,18 @@ __global__ __launch_bounds__(256) void ln_bwd8_kernel(const bf16* __restrict__ d
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int col = lane * 8 + c * 512;
-        if (col < H) {
+        const bool use = live && col < H;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float d = bf2f(dv[q][c][e]);
-            if (dh_b) d += bf2f(ev[q][c][e]);
-            if (!live) d = 0.f;
-            const float x = (bf2f(yv[q][c][e]) - mean) * rs[q];
-            xh[q][c][e] = x;
-            ag[c][e] += d * x; ab[c][e] += d;
-            const float gg = d * gm[c][e];
-            g[q][c][e] = gg;
-            s1[q] += gg; s2[q] += gg * x;
-          }
+        for (int e = 0; e < 8; ++e) {
+          float d = bf2f(dv[q][c][e]);
+          if (HASB) d += bf2f(ev[q][c][e]);
+          d = use ? d : 0.f;
+          const float x = (bf2f(yv[q][c][e]) - mean) * rs[q];
+          xh[q][c][e] = x;
+          ag[c][e] += d * x; ab[c][e] += d;
+          const float gg = d * gm[c][e];
+          g[q][c][e] = gg;
+          s1[q] += gg; s2[q] += gg * x;
         }
       }
     }
@@ -717,11 +718,12 @@ extern "C" int mmsim_ln_bwd(const void* dh_a, const void* dh_b, const void* y, c
                      (const bf16*)y, mean, rstd, gamma, (bf16*)dy, (bf16*)dt, scratch, M, H, rpw,                  \
                      make_drop(dropout_p, seed, stream_id))
   if (H % 8 == 0 && H <= 1024) {
-#define LN_BWD8_LAUNCH(NCV)                                                                                          \
-  hipLaunchKernelGGL((ln_bwd8_kernel<NCV>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16*)dh_a, (const bf16*)dh_b, \
+#define LN_BWD8_LAUNCH(NCV, HB)                                                                                      \
+  hipLaunchKernelGGL((ln_bwd8_kernel<NCV, HB>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16*)dh_a, (const bf16*)dh_b, \
                      (const bf16*)y, mean, rstd, gamma, (bf16*)dy, (bf16*)dt, scratch, M, H, rpw,                  \
                      make_drop(dropout_p, seed, stream_id))
-    if (H <= 512) LN_BWD8_LAUNCH(1); else LN_BWD8_LAUNCH(2);
+    if (H <= 512) { if (dh_b) LN_BWD8_LAUNCH(1, true); else LN_BWD8_LAUNCH(1, false); }
+    else { if (dh_b) LN_BWD8_LAUNCH(2, true); else LN_BWD8_LAUNCH(2, false); }
 #undef LN_BWD8_LAUNCH
   } else {
   const int nc = (H + 255) / 256;
