@@ -197,6 +197,14 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p) {
 #define PP64_A_IN_MFMA 1          // gemm_pp64_kernel: A_{u+2}'s LDS-DMA pieces issued between the odd step's MFMAs (see the kernel)
 #endif
 #define PP64_B_IN_MFMA 0          // B_{u+1} cannot move the same way: it would be issued and awaited within one step
+// PP64_B_SPLIT: the second half of B_{u+1}'s LDS-DMA pieces is issued right behind the even step's first MFMAs (after MFMA rows 0
+// and 1) instead of in its load phase, which then carries two pieces instead of four; they still have the rest of that MFMA phase and
+// the odd step's load phase (~650 cycles) before the wait for slice u + 1.  Measured r03 (tools/bench_gemm.py, alternating builds on
+// one box): weight-gradient layout +2-3 % (qkv 902-923 -> 937-943, ffn1 1 070 -> 1 090-1 110, o 695-706 -> 704-720 TFLOP/s), forward
+// layout -2-3 %, data-gradient layout +-2 %: on for the weight-gradient layout (A transposed, B k-rows) only.
+#ifndef PP64_B_SPLIT
+#define PP64_B_SPLIT 1
+#endif
 
 // Main-loop ablation switches (no DMA / no MFMA / no epilogue) exist ONLY in the separately compiled ablation object
 // (-DMMSIM_ABLATE, tools/bench_gemm_abl.py builds it next to the product library): the product binary has no such code path.
@@ -408,10 +416,46 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
       PP64_MFMA_B()
     }
 #else
-    if (u + 1 < ns && dma_on)
-      dma_tile<!TB_KMAJOR, BN>(gB, gldb, n0, kbeg + (u + 1) * 64, smem + B_OFF + ((u + 1) & 1) * B_UNIT, wave, lane);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    PP64_MFMA()
+    if constexpr (PP64_B_SPLIT && TA && !TB_KMAJOR) {
+      const bool doB = u + 1 < ns && dma_on;
+      char* bdst = smem + B_OFF + ((u + 1) & 1) * B_UNIT;
+      if (doB) {
+#pragma unroll
+        for (int i = 0; i < B_LPU / 2; ++i) {
+          __builtin_amdgcn_global_load_lds((glb_void_ptr)bsrc[i], (lds_void_ptr)(bdst + (wave * B_LPU + i) * 1024), 16, 0, 0);
+          bsrc[i] += bstep;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        if (i < B_LPU / 2 && doB) {
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_global_load_lds((glb_void_ptr)bsrc[B_LPU / 2 + i], (lds_void_ptr)(bdst + (wave * B_LPU + B_LPU / 2 + i) * 1024), 16, 0, 0);
+          bsrc[B_LPU / 2 + i] += bstep;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr (COLSUM_OK) {
+        if (do_colsum) {
+          if (wn == 0) { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[0], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[1], bacc[1], 0, 0, 0); }
+          else if (wn == 1) { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[2], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[3], bacc[1], 0, 0, 0); }
+          else if (wn == 2) { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 4 : 0], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 5 : 1], bacc[1], 0, 0, 0); }
+          else { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 6 : 2], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 7 : 3], bacc[1], 0, 0, 0); }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      if (u + 1 < ns && dma_on)
+        dma_tile<!TB_KMAJOR, BN>(gB, gldb, n0, kbeg + (u + 1) * 64, smem + B_OFF + ((u + 1) & 1) * B_UNIT, wave, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PP64_MFMA()
+    }
 #endif
     // ---- odd step: k-half 1 of slice u
     __builtin_amdgcn_s_barrier();
