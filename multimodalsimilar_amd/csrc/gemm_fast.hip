@@ -205,6 +205,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p) {
 #ifndef PP64_B_SPLIT
 #define PP64_B_SPLIT 1
 #endif
+#ifndef PP64_B_KEEP
+#define PP64_B_KEEP 2             // pieces (of four at BN = 256) that stay in the load phase; the others follow MFMA rows 0, 1, ...
+                                  // (1 measured the same as 2, 0 about 1 % below them on the weight-gradient products)
+#endif
 
 // Main-loop ablation switches (no DMA / no MFMA / no epilogue) exist ONLY in the separately compiled ablation object
 // (-DMMSIM_ABLATE, tools/bench_gemm_abl.py builds it next to the product library): the product binary has no such code path.
@@ -419,9 +423,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     if constexpr (PP64_B_SPLIT && TA && !TB_KMAJOR) {
       const bool doB = u + 1 < ns && dma_on;
       char* bdst = smem + B_OFF + ((u + 1) & 1) * B_UNIT;
+      constexpr int BKEEP = B_LPU == 4 ? PP64_B_KEEP : B_LPU / 2;
       if (doB) {
 #pragma unroll
-        for (int i = 0; i < B_LPU / 2; ++i) {
+        for (int i = 0; i < BKEEP; ++i) {
           __builtin_amdgcn_global_load_lds((glb_void_ptr)bsrc[i], (lds_void_ptr)(bdst + (wave * B_LPU + i) * 1024), 16, 0, 0);
           bsrc[i] += bstep;
         }
@@ -434,10 +439,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        if (i < B_LPU / 2 && doB) {
+        if (i < B_LPU - BKEEP && doB) {
           __builtin_amdgcn_sched_barrier(0);
-          __builtin_amdgcn_global_load_lds((glb_void_ptr)bsrc[B_LPU / 2 + i], (lds_void_ptr)(bdst + (wave * B_LPU + B_LPU / 2 + i) * 1024), 16, 0, 0);
-          bsrc[B_LPU / 2 + i] += bstep;
+          __builtin_amdgcn_global_load_lds((glb_void_ptr)bsrc[BKEEP + i], (lds_void_ptr)(bdst + (wave * B_LPU + BKEEP + i) * 1024), 16, 0, 0);
+          bsrc[BKEEP + i] += bstep;
           __builtin_amdgcn_sched_barrier(0);
         }
       }
