@@ -136,7 +136,10 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(ATTN_FW
       sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], sacc[kt], 0, 0, 0);
     }
   }
-  // softmax over keys: this lane holds keys {32kt + (r&3) + 8(r>>2) + 4hh}, partner lane^32 the rest
+  // softmax over keys: this lane holds keys {32kt + (r&3) + 8(r>>2) + 4hh}, partner lane^32 the rest.
+  // (Round 3, measured and not kept: scores in log2 units and UNNORMALISED probabilities into the P V product, 1 / sum and 1 / keep
+  // applied to the 32 outputs per lane -- 61.8 -> 59.9 us, but the reference-golden pooled-embedding error of the roberta-base-shaped
+  // fixture moved from 0.0081 to 0.0090 of its 0.01 bound: 0.05 ms per step is not worth that margin.)
   float mx = -3.0e38f;
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt)
