@@ -115,17 +115,23 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* dout, con
                                                            const float* word, const float* pos, const float* type,
                                                            const float* gamma, float* dword, float* dpos, float* dtype,
                                                            float* dgamma, float* dbeta, int B, int S, int H, float eps,
-                                                           int bchunk, Drop dr, int vocab, int tvocab, int max_pos, int* err, int serial) {
+                                                           int bchunk, Drop dr, int vocab, int tvocab, int max_pos, int* err, int serial,
+                                                           float* parts) {
   __shared__ __attribute__((aligned(16))) float rowbuf[4][MAXC * 256];       // one d(embedding) row per wave
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nchunks = (B + bchunk - 1) / bchunk;
   // serial (deterministic mode): ONE wave walks every (position, batch chunk) in order, so every atomic below has a single
   // adder issuing in program order; otherwise a wave per (position, batch chunk)
   const int gw_first = serial ? 0 : blockIdx.x * 4 + wv, gw_last = serial ? S * nchunks : gw_first + 1;
-  if (serial ? (blockIdx.x != 0 || wv != 0) : (gw_first >= S * nchunks)) return;
+  const bool idle = serial ? (blockIdx.x != 0 || wv != 0) : (gw_first >= S * nchunks);
+  if (idle && !parts) return;
+  // Column sums that EVERY wave contributes to (dgamma, dbeta, the two token-type rows): with `parts` (never in the serial mode; one trip
+  // of the loop below per wave) they leave through the workgroup's LDS into one slab row per workgroup, summed by
+  // row_reduce_partials_kernel -- an idle wave of the last workgroup walks an empty row range and adds zeros.  As atomics they were
+  // 2 048 adds per address at B = 256, S = 128, ~150 ns each, one after the other: 310 of the kernel's 460 us (r03, tools/bench_embed.py).
 #pragma unroll 1
   for (int gw = gw_first; gw < gw_last; ++gw) {
-  const int sw = gw % S, b0 = (gw / S) * bchunk, b1 = min(B, b0 + bchunk);
+  const int sw = gw % S, b0 = (gw / S) * bchunk, b1 = idle ? b0 : min(B, b0 + bchunk);
   float4 apos[MAXC], at0[MAXC], at1[MAXC], ag[MAXC], ab[MAXC];
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) apos[c] = at0[c] = at1[c] = ag[c] = ab[c] = make_float4(0, 0, 0, 0);
@@ -202,7 +208,8 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* dout, con
     const int col = lane * 4 + c * 256;
     if (col < H) {
       float* a = dpos + (size_t)sw * H + col;
-      if (!pids) { atomicAdd(a, apos[c].x); atomicAdd(a + 1, apos[c].y); atomicAdd(a + 2, apos[c].z); atomicAdd(a + 3, apos[c].w); }
+      if (!pids && !idle) { atomicAdd(a, apos[c].x); atomicAdd(a + 1, apos[c].y); atomicAdd(a + 2, apos[c].z); atomicAdd(a + 3, apos[c].w); }
+      if (parts) continue;
       a = dtype + col;
       atomicAdd(a, at0[c].x); atomicAdd(a + 1, at0[c].y); atomicAdd(a + 2, at0[c].z); atomicAdd(a + 3, at0[c].w);
       a = dtype + H + col;
@@ -211,6 +218,25 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* dout, con
       atomicAdd(a, ag[c].x); atomicAdd(a + 1, ag[c].y); atomicAdd(a + 2, ag[c].z); atomicAdd(a + 3, ag[c].w);
       a = dbeta + col;
       atomicAdd(a, ab[c].x); atomicAdd(a + 1, ab[c].y); atomicAdd(a + 2, ab[c].z); atomicAdd(a + 3, ab[c].w);
+    }
+  }
+  if (parts) {      // workgroup-uniform: slab row [4][H] = dgamma | dbeta | dtype[0] | dtype[1] of this workgroup
+    float* slab = parts + (size_t)blockIdx.x * 4 * H;
+#pragma unroll
+    for (int vec = 0; vec < 4; ++vec) {
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        const int col = lane * 4 + c * 256;
+        if (col < H) *reinterpret_cast<float4*>(rowbuf[wv] + col) = vec == 0 ? ag[c] : vec == 1 ? ab[c] : vec == 2 ? at0[c] : at1[c];
+      }
+      __syncthreads();
+      for (int col = threadIdx.x * 4; col < H; col += 1024) {
+        const float4 a = *reinterpret_cast<const float4*>(rowbuf[0] + col), b = *reinterpret_cast<const float4*>(rowbuf[1] + col);
+        const float4 c4 = *reinterpret_cast<const float4*>(rowbuf[2] + col), d = *reinterpret_cast<const float4*>(rowbuf[3] + col);
+        *reinterpret_cast<float4*>(slab + (size_t)vec * H + col) = make_float4((a.x + b.x) + (c4.x + d.x), (a.y + b.y) + (c4.y + d.y),
+                                                                               (a.z + b.z) + (c4.z + d.z), (a.w + b.w) + (c4.w + d.w));
+      }
     }
   }
   }
@@ -346,7 +372,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd8_kernel(const bf16* __restrict
 // out[i] += sum_p parts[p*part_stride + i]  (64 outputs x 4 waves per block; gridDim.y part-chunks, one atomic each)
 // The slab row holds up to three vectors of H columns back to back (dgamma | dbeta | dbias): ONE launch reduces all of them, the
 // output pointer is chosen per column (a NULL output is skipped).
-struct RowOuts { float* o[3]; int H; };
+struct RowOuts { float* o[4]; int H; };
 template <bool ATOMIC>
 __global__ __launch_bounds__(256) void row_reduce_partials_kernel(const float* __restrict__ parts, int nparts, size_t part_stride,
                                                                   int n, RowOuts outs) {
@@ -354,7 +380,7 @@ __global__ __launch_bounds__(256) void row_reduce_partials_kernel(const float* _
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   const int kk = i < n ? i / outs.H : 0;
-  float* out = (kk == 0 ? outs.o[0] : kk == 1 ? outs.o[1] : outs.o[2]);
+  float* out = (kk == 0 ? outs.o[0] : kk == 1 ? outs.o[1] : kk == 2 ? outs.o[2] : outs.o[3]);
   if (out) out -= (size_t)kk * outs.H;          // so that out[i] addresses column i - kk*H of vector kk
   float a0 = 0.f, a1 = 0.f;
   if (i < n) {
@@ -669,7 +695,8 @@ extern "C" int mmsim_embed_ln_bwd(const void* dout, const long long* ids, const 
                                   const float* word, const float* pos, const float* type, const float* gamma, float* dword,
                                   float* dpos, float* dtype, float* dgamma, float* dbeta, int B, int S, int H, int vocab_size,
                                   int type_vocab_size, int max_positions, int* err_flag, float eps, float dropout_p,
-                                  unsigned long long seed, unsigned int stream_id, void* stream) {
+                                  unsigned long long seed, unsigned int stream_id, float* scratch, unsigned long long scratch_floats,
+                                  void* stream) {
   MMSIM_REQUIRE(dout && ids && word && dword && dpos && dtype && dgamma && dbeta && err_flag, "embed_ln_bwd: null operand");
   MMSIM_REQUIRE(H % 4 == 0 && H <= 256 * MAXC, "embed_ln_bwd: H must be a multiple of 4 and <= 2048");
   MMSIM_REQUIRE(vocab_size > 0 && type_vocab_size > 0 && type_vocab_size <= 2 && max_positions > 0,
@@ -677,10 +704,21 @@ extern "C" int mmsim_embed_ln_bwd(const void* dout, const long long* ids, const 
   const int serial = mmsim_deterministic();
   const int bchunk = B >= 64 ? 16 : (B >= 8 ? 4 : 1);
   const int nw = serial ? 1 : S * ((B + bchunk - 1) / bchunk);
-  hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3((nw + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout,
+  const int nblk = (nw + 3) / 4;
+  // the sums every wave adds to (dgamma, dbeta, the token-type rows) go through per-workgroup slab rows when the caller lends the
+  // scratch for them (nblk x 4H floats); without it -- and in the deterministic single-wave mode -- they are atomics as before
+  float* parts = (!serial && scratch && scratch_floats >= (unsigned long long)nblk * 4 * H) ? scratch : nullptr;
+  hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout,
                      (const int64_t*)ids, (const int64_t*)token_types, (const int64_t*)position_ids, word, pos, type, gamma, dword, dpos,
                      dtype, dgamma, dbeta, B, S, H, eps, bchunk, make_drop(dropout_p, seed, stream_id), vocab_size, type_vocab_size,
-                     max_positions, err_flag, serial);
+                     max_positions, err_flag, serial, parts);
+  if (parts) {
+    RowOuts outs;
+    outs.o[0] = dgamma; outs.o[1] = dbeta; outs.o[2] = dtype; outs.o[3] = dtype + H; outs.H = H;
+    int gy = nblk / 16; if (gy > 8) gy = 8; if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(row_reduce_partials_kernel<true>, dim3((4 * H + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream,
+                       parts, nblk, (size_t)4 * H, 4 * H, outs);
+  }
   return mmsim_check_launch("embed_ln_bwd");
 }
 
@@ -732,7 +770,7 @@ extern "C" int mmsim_ln_bwd(const void* dh_a, const void* dh_b, const void* y, c
   }
 #undef LN_BWD_LAUNCH
   RowOuts outs;
-  outs.o[0] = dgamma; outs.o[1] = dbeta; outs.o[2] = dbias; outs.H = H;
+  outs.o[0] = dgamma; outs.o[1] = dbeta; outs.o[2] = dbias; outs.o[3] = nullptr; outs.H = H;
   int gy = nblk / 16; if (gy > 8) gy = 8; if (gy < 1) gy = 1;
   if (mmsim_deterministic())
     hipLaunchKernelGGL(row_reduce_partials_kernel<false>, dim3((3 * H + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream,
