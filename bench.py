@@ -163,7 +163,13 @@ def main():
     ap.add_argument("--ragged-masks", action="store_true", help="per-row sequence lengths ~ U{8..S} (SURVEY 8d realism run; not the headline)")
     ap.add_argument("--literal-loss", action="store_true", help="materialised logits + nn.CrossEntropyLoss instead of the fused head")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python (eager) instead of replaying the captured hipGraph")
+    ap.add_argument("--shard-head-from", type=int, default=None, help="classes from which an N > 1 run shards the ArcFace head over ranks (default 500000; 100000 shards cfg4's)")
+    ap.add_argument("--grad-dtype", choices=("fp32", "bf16"), default=None, help="element type of the gradient all-reduce buckets (default fp32)")
     args = ap.parse_args()
+    if args.shard_head_from is not None:
+        os.environ["MMSIM_SHARD_HEAD_FROM"] = str(args.shard_head_from)       # read by multimodalsimilar_amd.train at import
+    if args.grad_dtype is not None:
+        os.environ["MMSIM_GRAD_DTYPE"] = args.grad_dtype                      # read by GradientExchange
 
     # before the first HIP call of the process: the host driver only supports dmabuf IPC (RCCL / cross-process tensors)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -300,6 +306,7 @@ def main():
                        "dist_backend": dist.get_backend() if world > 1 else None,
                        "ranks_in_process_group": dist.get_world_size() if world > 1 else 1,
                        "head": type(model.classifier).__name__,
+                       "grad_exchange_dtype": (str(step.exchange.grad_dtype).replace("torch.", "") if step.exchange else None),
                        "image": cfg.get("res"), "classes": cfg["classes"], "parallelism": f"dp{world}",
                        "dropout": not args.no_dropout, "attention_mask": "ragged U{8..S}" if args.ragged_masks else "all ones", "loss_path": "literal" if args.literal_loss else "fused",
                        "algorithmic_gflop_per_pair": fpp / 1e9,

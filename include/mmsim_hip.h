@@ -21,6 +21,8 @@ extern "C" {
 #endif
 
 /* ---- library state -------------------------------------------------------------------------- */
+/* 300 = this header (fp16 forward tensors in the image-tower entry points, mmsim_embed_ln_bwd2, mmsim_adamw_step2); a binding built
+ * from an older header must check mmsim_version() < 300 before passing bf16 image tensors. */
 int mmsim_version(void);
 int mmsim_device_count(void);
 const char* mmsim_last_error(void);
@@ -128,20 +130,29 @@ int mmsim_attn_bwd_dbias(const void* qkv, int ld_qkv, const long long* mask, con
  * tables and gamma/beta fp32; out bf16 [B*S,H].  vocab_size / type_vocab_size (<= 2) / max_positions are the table
  * heights: an index outside its table sets *err_flag (device int, never cleared by the kernels; nn.Embedding raises an
  * IndexError there) and is clamped, so neither the gather nor the backward's scatter-add leaves its table.
- * Backward accumulates (atomically) into dword [V,H], dpos [P,H], dtype [2,H], dgamma, dbeta (fp32, pre-zeroed).  `scratch`
- * (optional, >= ceil(S * ceil(B / c) / 4) * 4H floats with c = 16 for B >= 64, 4 for B >= 8, else 1; smaller: ignored): the sums every wave adds to -- dgamma, dbeta, the token-type rows -- then
- * leave through one slab row per workgroup and a small reduction instead of thousands of same-address atomics. */
+ * Backward accumulates (atomically) into dword [V,H], dpos [P,H], dtype [type_vocab_size,H], dgamma, dbeta (fp32, pre-zeroed).
+ * `scratch` (mmsim_embed_ln_bwd2; optional, >= mmsim_embed_ln_bwd_scratch_floats(B, S, H) floats; smaller or NULL: ignored): the sums
+ * every wave adds to -- dgamma, dbeta, the token-type rows -- then leave through one slab row per workgroup and a small reduction
+ * instead of thousands of same-address atomics. */
 int mmsim_embed_ln_fwd(const long long* ids, const long long* token_types, const long long* position_ids,
                        const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
                        void* out, int B, int S, int H, int vocab_size, int type_vocab_size, int max_positions,
                        int* err_flag, float eps, float dropout_p, unsigned long long seed, unsigned int stream_id,
                        void* stream);
+int mmsim_embed_ln_bwd2(const void* dout, const long long* ids, const long long* token_types, const long long* position_ids,
+                        const float* word, const float* pos, const float* type, const float* gamma, float* dword,
+                        float* dpos, float* dtype, float* dgamma, float* dbeta, int B, int S, int H, int vocab_size,
+                        int type_vocab_size, int max_positions, int* err_flag, float eps, float dropout_p,
+                        unsigned long long seed, unsigned int stream_id, float* scratch, unsigned long long scratch_floats,
+                        void* stream);
+/* floats of `scratch` the slab path of mmsim_embed_ln_bwd2 needs for this shape (the library's own batch split; 0 for an empty shape) */
+int mmsim_embed_ln_bwd_scratch_floats(int B, int S, int H);
+/* The version-200 signature (no scratch: atomics only), kept so that a binding generated from the older header keeps working. */
 int mmsim_embed_ln_bwd(const void* dout, const long long* ids, const long long* token_types, const long long* position_ids,
                        const float* word, const float* pos, const float* type, const float* gamma, float* dword,
                        float* dpos, float* dtype, float* dgamma, float* dbeta, int B, int S, int H, int vocab_size,
                        int type_vocab_size, int max_positions, int* err_flag, float eps, float dropout_p,
-                       unsigned long long seed, unsigned int stream_id, float* scratch, unsigned long long scratch_floats,
-                       void* stream);
+                       unsigned long long seed, unsigned int stream_id, void* stream);
 
 /* ---- y = dropout(t) + resid ; h = LayerNorm(y)  (BertSelfOutput / BertOutput, modeling_bert.py:289-293, 347-351).
  * t, resid, y, h: bf16 [M,H]; mean/rstd: fp32 [M] saved for backward. */

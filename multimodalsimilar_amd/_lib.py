@@ -15,6 +15,9 @@ _SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "unsigned long long": 
             "unsigned int": ctypes.c_uint32, "long long": ctypes.c_int64}
 
 
+MIN_VERSION = 300      # include/mmsim_hip.h: the header this binding is generated from
+
+
 class MmsimError(RuntimeError):
     pass
 
@@ -59,6 +62,10 @@ class _Lib:
                 f"{LIBPATH} not found: the HIP library has not been built "
                 "(run `python -m multimodalsimilar_amd.build`); there is no CPU fallback")
         self._dll = ctypes.CDLL(LIBPATH)
+        self._dll.mmsim_version.restype = ctypes.c_int
+        if self._dll.mmsim_version() < MIN_VERSION:
+            raise MmsimError(f"{LIBPATH} is version {self._dll.mmsim_version()}, this binding needs >= {MIN_VERSION} "
+                             "(fp16 image-tower tensors, mmsim_embed_ln_bwd2): rebuild with `python -m multimodalsimilar_amd.build`")
         self._decls = parse_header()
         for name, (restype, argl) in self._decls.items():
             fn = getattr(self._dll, name)   # AttributeError if the .so does not export a declared symbol
@@ -88,6 +95,6 @@ class _Lib:
 
 
 # entry points whose int return is a value, not a status (plus every *_eligible predicate)
-_VALUE_RETURNING = ("version", "device_count", "get_deterministic")
+_VALUE_RETURNING = ("version", "device_count", "get_deterministic", "embed_ln_bwd_scratch_floats")
 
 lib = _Lib()

@@ -102,8 +102,15 @@ __device__ __forceinline__ void wave_sum4(float& a, float& b, float& c, float& d
   a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64); c += __shfl_xor(c, 16, 64); d += __shfl_xor(d, 16, 64);
   a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64); c += __shfl_xor(c, 32, 64); d += __shfl_xor(d, 32, 64);
 }
+// The maximum must not see the zero a bound_ctrl DPP move supplies for a lane that EXEC disables (all-negative rows: masked softmax
+// scores): update_dpp with old = v and bound_ctrl off makes a disabled / invalid source return the lane's OWN value, the identity
+// of max.  (The sums keep bound_ctrl = zero, their identity.)
+template <int CTRL> __device__ __forceinline__ float dpp_self_f(float x) {
+  const int xi = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float wave_max(float v) {
-  v = fmaxf(v, dpp_mov_f<0xB1>(v)); v = fmaxf(v, dpp_mov_f<0x4E>(v)); v = fmaxf(v, dpp_mov_f<0x141>(v)); v = fmaxf(v, dpp_mov_f<0x140>(v));
+  v = fmaxf(v, dpp_self_f<0xB1>(v)); v = fmaxf(v, dpp_self_f<0x4E>(v)); v = fmaxf(v, dpp_self_f<0x141>(v)); v = fmaxf(v, dpp_self_f<0x140>(v));
   v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }

@@ -46,7 +46,9 @@ static const unsigned long long* g_step_seed_ptr = nullptr;
 extern "C" int mmsim_set_step_seed_ptr(const unsigned long long* dev_ptr) { g_step_seed_ptr = dev_ptr; return MMSIM_OK; }
 const unsigned long long* mmsim_step_seed_ptr(void) { return g_step_seed_ptr; }
 
-extern "C" int mmsim_version(void) { return 200; }
+// 300: the image tower's forward tensors are fp16 (the *_bf16-named image entry points read fp16 where the header says so) and
+// mmsim_embed_ln_bwd2 / mmsim_adamw_step2 exist; a binding generated from an older header must refuse a library >= 300.
+extern "C" int mmsim_version(void) { return 300; }
 
 // Returns the number of visible HIP devices, or -1 with the error string set.
 extern "C" int mmsim_device_count(void) {

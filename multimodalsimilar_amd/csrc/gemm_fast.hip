@@ -205,6 +205,22 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p) {
 #ifndef PP64_B_SPLIT
 #define PP64_B_SPLIT 1
 #endif
+// PP64_BAL (round 4): the BALANCED schedule.  The B fragments of a whole 64-deep slice are read in the even step (8 instead of 4
+// fragment registers sets), which frees B's ring slot half a slice earlier, so that B_{u+2} -- not B_{u+1} -- is what a slice
+// issues and EVERY LDS-DMA piece has more than a slice of time to land.  The eight pieces of a slice are then spread evenly over
+// the four phases: two per load phase (where a piece costs ~130 issue cycles but runs under the partner wave's MFMA phase) and
+// two per MFMA phase (~40 cycles each, exposed), instead of 4 + 0 + 0 + 4: with the measured costs the four intervals of a slice
+// were 770 | 770 | 512 | 670 cycles (max of the two groups' phases) and become ~590 each.
+//   even step 2u:   B1 | read B (both k-halves) and A k-half 0 of slice u; issue A_{u+2} pieces 0, 1;                 lgkmcnt(0) | B2 | MFMAs + A_{u+2} pieces 2, 3
+//   odd  step 2u+1: B1 | read A k-half 1 of slice u; issue B_{u+2} first half; vmcnt(|A| + |B| / 2);                  lgkmcnt(0) | B2 | MFMAs + B_{u+2} second half
+// WAR: A_{u+2} -> slot of A_{u-1}, last read in the lagging group's odd load phase of slice u - 1, which ends at the barrier that
+// opens the leading group's even load phase of slice u; B_{u+2} -> slot of B_u, last read in the lagging group's even load phase
+// of slice u, which ends at the barrier that opens the leading group's odd load phase.  RAW: slice u + 1 (A_{u+1} from the even
+// phases, B_{u+1} from the odd phases of slice u - 1; A_1 | B_1 from the prologue) is waited for at the end of the odd LOAD phase of
+// slice u, where exactly A_{u+2} and the first half of B_{u+2} are younger.
+#ifndef PP64_BAL
+#define PP64_BAL 1
+#endif
 #ifndef PP64_B_KEEP
 #define PP64_B_KEEP 2             // pieces (of four at BN = 256) that stay in the load phase; the others follow MFMA rows 0, 1, ...
                                   // (1 measured the same as 2, 0 about 1 % below them on the weight-gradient products)
@@ -308,15 +324,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
   const bool dma_on = !(PP64_DBG(p) & 1);
+  constexpr int B_LPU = BN * 128 / (8 * 1024);             // LDS-DMA pieces per wave per B unit (4 or 2)
   if (dma_on) {
     dma_tile<TA, GBM>(gA, glda, m0, kbeg, smem, wave, lane);
     dma_tile<!TB_KMAJOR, BN>(gB, gldb, n0, kbeg, smem + B_OFF, wave, lane);
     if (ns > 1) dma_tile<TA, GBM>(gA, glda, m0, kbeg + 64, smem + A_UNIT, wave, lane);
+#if PP64_BAL
+    if (ns > 1) dma_tile<!TB_KMAJOR, BN>(gB, gldb, n0, kbeg + 64, smem + B_OFF + B_UNIT, wave, lane);
+#endif
   }
+#if PP64_BAL
+  if (ns > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LPU + B_LPU) : "memory");
+#else
   if (ns > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LPU) : "memory");
+#endif
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (grp == 1) __builtin_amdgcn_s_barrier();            // the anti-phase offset
-  bf8 af[MT], bfr[4];
+  bf8 af[MT], bfr[PP64_BAL ? 8 : 4];
   int sa = 0;                                            // A slot of slice u (u mod 3)
 #define PP64_READ(KS)                                                                                    \
   {                                                                                                      \
@@ -360,19 +384,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     }
   }
   const size_t astep = TA ? (size_t)64 * glda : (size_t)64;
-  constexpr int B_LPU = BN * 128 / (8 * 1024);             // LDS-DMA pieces per wave per B unit (4 or 2)
-  const bf16* bsrc[B_LPU];                                 // the same for B: piece i of slice 1 first
+  const bf16* bsrc[B_LPU];                                 // the same for B: piece i of slice 1 (balanced schedule: 2) first
+  constexpr int BS0 = PP64_BAL ? 128 : 64;
   {
 #pragma unroll
     for (int i = 0; i < B_LPU; ++i) {
       const int blk = wave * B_LPU + i;
       if (TB_KMAJOR) {
         const int row = blk * 8 + (lane >> 3), pos = lane & 7;
-        bsrc[i] = gB + (size_t)(n0 + row) * gldb + kbeg + 64 + (pos ^ ((row >> 1) & 7)) * 8;
+        bsrc[i] = gB + (size_t)(n0 + row) * gldb + kbeg + BS0 + (pos ^ ((row >> 1) & 7)) * 8;
       } else {
         constexpr int CPR = BN / 8, RPB = 64 / CPR;
         const int k = blk * RPB + lane / CPR, pc = lane % CPR;
-        bsrc[i] = gB + (size_t)(kbeg + 64 + k) * gldb + n0 + ((((pc >> 1) ^ ftr_key(k)) << 1) | (pc & 1)) * 8;
+        bsrc[i] = gB + (size_t)(kbeg + BS0 + k) * gldb + n0 + ((((pc >> 1) ^ ftr_key(k)) << 1) | (pc & 1)) * 8;
       }
     }
   }
@@ -408,6 +432,92 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     }                                                                                                    \
   }                                                                                                      \
   __builtin_amdgcn_sched_barrier(0);
+#if PP64_BAL
+#define PP64_COLSUM()                                                                                    \
+    if constexpr (COLSUM_OK) {                                                                           \
+      if (do_colsum) {                                                                                   \
+        if (wn == 0) { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[0], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[1], bacc[1], 0, 0, 0); } \
+        else if (wn == 1) { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[2], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[3], bacc[1], 0, 0, 0); } \
+        else if (wn == 2) { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 4 : 0], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 5 : 1], bacc[1], 0, 0, 0); } \
+        else { bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 6 : 2], bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[MT > 4 ? 7 : 3], bacc[1], 0, 0, 0); } \
+      }                                                                                                  \
+    }
+  // MFMA phase of one 32-deep step with pieces [P0, P1) of one operand's next unit issued behind MFMA rows 1, MT/2 + 1, ... (early in
+  // the phase: a piece issued behind the last MFMAs would put its issue latency in front of the barrier)
+#define PP64_MFMA_BAL(JB, DOX, P0, P1, SRC, STEP, DST, NPW)                                              \
+  __builtin_amdgcn_s_barrier();                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                     \
+  if (!(PP64_DBG(p) & 4)) {                                                                              \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[JB + j], af[i], acc[i][j], 0, 0, 0);     \
+      constexpr int NPC = (P1) - (P0);                                                                   \
+      constexpr int GAP = NPC > 0 ? MT / NPC : MT;                                                       \
+      if (NPC > 0 && (i % GAP) == (GAP > 1 ? 1 : 0) && i / GAP < NPC && DOX) {                           \
+        const int pc = (P0) + i / GAP;                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)SRC[pc], (lds_void_ptr)(DST + (wave * NPW + pc) * 1024), 16, 0, 0); \
+        SRC[pc] += STEP;                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+      }                                                                                                  \
+    }                                                                                                    \
+    PP64_COLSUM()                                                                                        \
+  }                                                                                                      \
+  __builtin_amdgcn_sched_barrier(0);
+  for (int u = 0; u < ns; ++u) {
+    const bool donext = u + 2 < ns && dma_on;              // slice u + 2 exists: this slice issues A_{u+2} and B_{u+2}
+    int sn = sa + 2; if (sn >= 3) sn -= 3;
+    char* adst = smem + sn * A_UNIT;
+    char* bdst = smem + B_OFF + (u & 1) * B_UNIT;          // B_{u+2} takes B_u's slot
+    // ---- even step: B fragments of the whole slice, A fragments of k-half 0
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const char* la = smem + sa * A_UNIT;
+      const char* lb = smem + B_OFF + (u & 1) * B_UNIT;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = hfrag<!TB_KMAJOR, BN>(lb, wn * 64 + j * 16, 0, lane);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = hfrag<TA, GBM>(la, wm * WROWS + i * 16, 0, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[4 + j] = hfrag<!TB_KMAJOR, BN>(lb, wn * 64 + j * 16, 1, lane);
+    }
+    if (donext) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)asrc[i], (lds_void_ptr)(adst + (wave * 4 + i) * 1024), 16, 0, 0);
+        asrc[i] += astep;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP64_MFMA_BAL(0, donext, 2, 4, asrc, astep, adst, 4)
+    // ---- odd step: A fragments of k-half 1; B_u's slot is free (every wave has passed the barrier behind its even load phase)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const char* la = smem + sa * A_UNIT;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = hfrag<TA, GBM>(la, wm * WROWS + i * 16, 1, lane);
+    }
+    if (donext) {
+#pragma unroll
+      for (int i = 0; i < B_LPU / 2; ++i) {
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)bsrc[i], (lds_void_ptr)(bdst + (wave * B_LPU + i) * 1024), 16, 0, 0);
+        bsrc[i] += bstep;
+      }
+      // slice u + 1 landed: all but A_{u+2} and the first half of B_{u+2}.  BEFORE the barrier below -- the other wave group, one
+      // barrier ahead, reads slice u + 1 right behind it.
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LPU + B_LPU / 2) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP64_MFMA_BAL(4, donext, B_LPU / 2, B_LPU, bsrc, bstep, bdst, B_LPU)
+    sa = sa + 1; if (sa >= 3) sa = 0;
+  }
+#undef PP64_MFMA_BAL
+#undef PP64_COLSUM
+#else
   for (int u = 0; u < ns; ++u) {
     // ---- even step: k-half 0 of slice u
     __builtin_amdgcn_s_barrier();
@@ -491,6 +601,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
 #endif
     sa = sa + 1; if (sa >= 3) sa = 0;
   }
+#endif
 #undef PP64_MFMA_A
 #undef PP64_MFMA_B
 #undef PP64_MFMA_X

@@ -691,20 +691,43 @@ extern "C" int mmsim_embed_ln_fwd(const long long* ids, const long long* token_t
   return mmsim_check_launch("embed_ln_fwd");
 }
 
+// the batch split of embed_ln_bwd over waves: ONE definition, used by the launch and by the scratch-size query
+static int embed_bwd_bchunk(int B) { return B >= 64 ? 16 : (B >= 8 ? 4 : 1); }
+static int embed_bwd_blocks(int B, int S) { const int c = embed_bwd_bchunk(B); return (S * ((B + c - 1) / c) + 3) / 4; }
+extern "C" int mmsim_embed_ln_bwd_scratch_floats(int B, int S, int H) {
+  if (B <= 0 || S <= 0 || H <= 0) return 0;
+  const unsigned long long n = (unsigned long long)embed_bwd_blocks(B, S) * 4 * H;
+  return n > 0x7fffffffull ? 0x7fffffff : (int)n;
+}
+
+extern "C" int mmsim_embed_ln_bwd2(const void* dout, const long long* ids, const long long* token_types, const long long* position_ids,
+                                   const float* word, const float* pos, const float* type, const float* gamma, float* dword,
+                                   float* dpos, float* dtype, float* dgamma, float* dbeta, int B, int S, int H, int vocab_size,
+                                   int type_vocab_size, int max_positions, int* err_flag, float eps, float dropout_p,
+                                   unsigned long long seed, unsigned int stream_id, float* scratch, unsigned long long scratch_floats,
+                                   void* stream);
+// the pre-scratch signature, kept for bindings generated from the version-200 header: atomics-only path
 extern "C" int mmsim_embed_ln_bwd(const void* dout, const long long* ids, const long long* token_types, const long long* position_ids,
                                   const float* word, const float* pos, const float* type, const float* gamma, float* dword,
                                   float* dpos, float* dtype, float* dgamma, float* dbeta, int B, int S, int H, int vocab_size,
                                   int type_vocab_size, int max_positions, int* err_flag, float eps, float dropout_p,
-                                  unsigned long long seed, unsigned int stream_id, float* scratch, unsigned long long scratch_floats,
-                                  void* stream) {
+                                  unsigned long long seed, unsigned int stream_id, void* stream) {
+  return mmsim_embed_ln_bwd2(dout, ids, token_types, position_ids, word, pos, type, gamma, dword, dpos, dtype, dgamma, dbeta, B, S, H,
+                             vocab_size, type_vocab_size, max_positions, err_flag, eps, dropout_p, seed, stream_id, nullptr, 0, stream);
+}
+extern "C" int mmsim_embed_ln_bwd2(const void* dout, const long long* ids, const long long* token_types, const long long* position_ids,
+                                   const float* word, const float* pos, const float* type, const float* gamma, float* dword,
+                                   float* dpos, float* dtype, float* dgamma, float* dbeta, int B, int S, int H, int vocab_size,
+                                   int type_vocab_size, int max_positions, int* err_flag, float eps, float dropout_p,
+                                   unsigned long long seed, unsigned int stream_id, float* scratch, unsigned long long scratch_floats,
+                                   void* stream) {
   MMSIM_REQUIRE(dout && ids && word && dword && dpos && dtype && dgamma && dbeta && err_flag, "embed_ln_bwd: null operand");
   MMSIM_REQUIRE(H % 4 == 0 && H <= 256 * MAXC, "embed_ln_bwd: H must be a multiple of 4 and <= 2048");
   MMSIM_REQUIRE(vocab_size > 0 && type_vocab_size > 0 && type_vocab_size <= 2 && max_positions > 0,
                 "embed_ln_bwd: table sizes must be positive (at most two token types)");
   const int serial = mmsim_deterministic();
-  const int bchunk = B >= 64 ? 16 : (B >= 8 ? 4 : 1);
-  const int nw = serial ? 1 : S * ((B + bchunk - 1) / bchunk);
-  const int nblk = (nw + 3) / 4;
+  const int bchunk = embed_bwd_bchunk(B);
+  const int nblk = serial ? 1 : embed_bwd_blocks(B, S);
   // the sums every wave adds to (dgamma, dbeta, the token-type rows) go through per-workgroup slab rows when the caller lends the
   // scratch for them (nblk x 4H floats); without it -- and in the deterministic single-wave mode -- they are atomics as before
   float* parts = (!serial && scratch && scratch_floats >= (unsigned long long)nblk * 4 * H) ? scratch : nullptr;
@@ -714,7 +737,7 @@ extern "C" int mmsim_embed_ln_bwd(const void* dout, const long long* ids, const 
                      max_positions, err_flag, serial, parts);
   if (parts) {
     RowOuts outs;
-    outs.o[0] = dgamma; outs.o[1] = dbeta; outs.o[2] = dtype; outs.o[3] = dtype + H; outs.H = H;
+    outs.o[0] = dgamma; outs.o[1] = dbeta; outs.o[2] = dtype; outs.o[3] = type_vocab_size > 1 ? dtype + H : nullptr; outs.H = H;
     int gy = nblk / 16; if (gy > 8) gy = 8; if (gy < 1) gy = 1;
     hipLaunchKernelGGL(row_reduce_partials_kernel<true>, dim3((4 * H + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream,
                        parts, nblk, (size_t)4 * H, 4 * H, outs);

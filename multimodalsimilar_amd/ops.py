@@ -298,9 +298,8 @@ def embed_ln_bwd(dout, ids, tts, word, pos, typ, gamma, dword, dpos, dtype_, dga
     for t, n in ((dword, "dword"), (dpos, "dpos"), (dtype_, "dtype"), (dgamma, "dgamma"), (dbeta, "dbeta")):
         _chk(t, F32, "embed_bwd." + n)
     V, TV, P = _embed_tables(ids, tts, pids, word, pos, typ, err, B, S, "embed_bwd")
-    bchunk = 16 if B >= 64 else (4 if B >= 8 else 1)      # the library's split of the batch over waves
-    scr = _scratch(dout.device, ((S * ((B + bchunk - 1) // bchunk) + 3) // 4) * 4 * H)      # one slab row [4][H] per workgroup
-    lib.embed_ln_bwd(_p(dout), _p(ids), _p(tts), _p(pids), _p(word), _p(pos), _p(typ), _p(gamma), _p(dword), _p(dpos),
+    scr = _scratch(dout.device, lib.embed_ln_bwd_scratch_floats(B, S, H))      # one slab row [4][H] per workgroup (the library's count)
+    lib.embed_ln_bwd2(_p(dout), _p(ids), _p(tts), _p(pids), _p(word), _p(pos), _p(typ), _p(gamma), _p(dword), _p(dpos),
                      _p(dtype_), _p(dgamma), _p(dbeta), B, S, H, V, TV, P, _p(err), eps, float(dropout_p), seed, stream_id,
                      _p(scr), scr.numel(), _stream())
 

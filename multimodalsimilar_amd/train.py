@@ -11,6 +11,7 @@ AdamW(lr 1e-2) over the ArcFace head with 15 % (float) warm-up (:152-164) -- her
 flat parameter buffers.  Under data parallelism the flat gradient buffers are all-reduced (sum) over RCCL while
 backward is still running and the 1/world factor is folded into the AdamW kernels.
 """
+import os
 import warnings
 from types import SimpleNamespace
 
@@ -50,7 +51,10 @@ def text_config(name, dropout=True):
     raise ValueError(name)
 
 
-SHARD_HEAD_FROM = 500000      # classes from which a data-parallel run shards the head by default (BASELINE config 5: 1 M)
+# classes from which a data-parallel run shards the head by default (BASELINE config 5: 1 M).  MMSIM_SHARD_HEAD_FROM moves the
+# threshold (bench.py --shard-head-from): at cfg4 the replicated head's 1.1 GB gradient is 45 % of the bytes all-reduced per step,
+# with --shard-head-from 100000 it is exchanged as [B N, D] embeddings + [B N] row statistics instead.
+SHARD_HEAD_FROM = int(os.environ.get("MMSIM_SHARD_HEAD_FROM", "500000"))
 
 
 def _want_sharded_head(cfg):
@@ -58,7 +62,7 @@ def _want_sharded_head(cfg):
     on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     want = cfg.get("sharded_head")
     if want is None:
-        want = cfg["classes"] >= SHARD_HEAD_FROM
+        want = cfg["classes"] >= cfg.get("shard_head_from", SHARD_HEAD_FROM)
     return bool(want and on)
 
 
@@ -84,7 +88,7 @@ def _build_model(cfg, device, seed=0, dropout=True):
     from cv_classifier import CvClassifier
     from multimodal_classifier import MultimodalClassifier
     torch.manual_seed(seed)
-    c = SimpleNamespace(**{k: v for k, v in cfg.items() if k != "sharded_head"})
+    c = SimpleNamespace(**{k: v for k, v in cfg.items() if k not in ("sharded_head", "shard_head_from")})
     if c.kind == "nlp":
         return NlpClassifier(BertModel(text_config(c.text, dropout), seed=seed), num_labels=c.classes).to(device)
     with warnings.catch_warnings():

@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    # one parity log per session: rows of an earlier build or of tests that no longer exist must not survive.
+    # Worker processes of pytest-xdist share the file: only the controller truncates.
+    if not hasattr(session.config, "workerinput"):
+        import torch
+        if torch.cuda.is_available():
+            import parity_log
+            parity_log.start_session()
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():

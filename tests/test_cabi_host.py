@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     for name in decls:
         assert hasattr(dll, name), name
     lib.load()
-    assert lib.version() >= 100
+    assert lib.version() >= 300
 
 
 def test_validation_happens_before_launch_and_reports_message():

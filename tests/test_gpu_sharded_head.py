@@ -79,13 +79,17 @@ def _head_worker(rank, world, port, backend, out):
     dist.destroy_process_group()
 
 
-def _step_worker(rank, world, port, backend, out):
+def _step_worker(rank, world, port, backend, out, select="force"):
+    """select: how the run asks for the sharded head -- "force" (cfg["sharded_head"]) or "threshold" (cfg["shard_head_from"] <= classes,
+    what bench.py --shard-head-from / MMSIM_SHARD_HEAD_FROM set: VERDICT r3 item 8, cfg4's 100 000-class head sharded)."""
     dev = _setup(rank, world, port, backend)
     from multimodalsimilar_amd import train as T
     cfg = dict(kind="nlp", text="tiny", seq_len=32, batch=8, classes=250)
     res = {}
     for sharded in (False, True):
-        model = T.build_model(dict(cfg, sharded_head=sharded), dev, seed=0, dropout=False)
+        pick = dict(sharded_head=sharded) if select == "force" else dict(shard_head_from=200 if sharded else 10 ** 9)
+        model = T.build_model(dict(cfg, **pick), dev, seed=0, dropout=False)
+        assert (type(model.classifier).__name__ == "ShardedArcMarginProduct") == sharded
         ts = T.TrainStep(model, "nlp", 10)
         losses = []
         for i in range(3):
@@ -130,10 +134,11 @@ def test_sharded_head_matches_the_replicated_head(tmp_path, backend):
     assert open(out).read() == "ok"
 
 
+@pytest.mark.parametrize("select", ["force", "threshold"])
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
-def test_train_step_with_the_sharded_head_tracks_the_replicated_one(tmp_path, backend):
+def test_train_step_with_the_sharded_head_tracks_the_replicated_one(tmp_path, backend, select):
     if backend not in _backends():
         pytest.skip("RCCL needs one GPU per rank: fewer than 2 devices visible")
     out = str(tmp_path / "ok.txt")
-    mp.spawn(_step_worker, args=(2, _free_port(), backend, out), nprocs=2, join=True)
+    mp.spawn(_step_worker, args=(2, _free_port(), backend, out, select), nprocs=2, join=True)
     assert open(out).read() == "ok"

@@ -142,3 +142,26 @@ def test_shard_ranges_cover_the_classes_exactly():
     S = torch.stack([torch.tensor([[3.0, math.exp(-2.0) + 1.0, 0.0, 0.0]]), torch.tensor([[3.0, 1.0 + math.exp(-5.0), 3.0, 1.0]])])
     lse, zt, am = combine_row_stats(S, torch.tensor([[1], [2]]))
     assert torch.allclose(lse, torch.logsumexp(z, 1)) and zt.item() == 3.0 and am.item() == 1
+
+
+def _threshold_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodalsimilar_amd import train as T
+    cfg4 = dict(T.CONFIGS["cfg4"])
+    assert not T._want_sharded_head(cfg4)                                        # 100 000 classes: below the default threshold
+    assert T._want_sharded_head(dict(cfg4, shard_head_from=100000))             # bench.py --shard-head-from 100000
+    assert not T._want_sharded_head(dict(cfg4, shard_head_from=100000, sharded_head=False))      # the explicit switch wins
+    assert T._want_sharded_head(dict(T.CONFIGS["cfg5"]))                         # 1 M classes: sharded by default
+    assert T._want_sharded_head(dict(cfg4, sharded_head=True))
+    if rank == 0:
+        open(out, "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_shard_threshold_selects_the_head_under_data_parallelism(tmp_path):
+    out = str(tmp_path / "ok.txt")
+    mp.spawn(_threshold_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+    from multimodalsimilar_amd import train as T
+    assert not T._want_sharded_head(dict(T.CONFIGS["cfg5"]))                     # single process: never sharded

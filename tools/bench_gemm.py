@@ -33,7 +33,14 @@ for name, N, K in shapes:
     t_nn = bench(lambda: ops.gemm(dy, w, dx, b_kmajor=False))
     t_tn = bench(lambda: ops.gemm(dy, x, dw, trans_a=True, b_kmajor=False, split_k=sk, accumulate=True))
     t_ref = bench(lambda: torch.matmul(x, w.t()))
+    # the outputs of the LAST timed launches, re-checked in full: a race between the wave groups only shows under load
+    ref = x.float() @ w.float().t(); e_nt2 = ((y.float() - ref).abs().max() / ref.abs().max()).item()
+    ref = dy.float() @ w.float(); e_nn2 = ((dx.float() - ref).abs().max() / ref.abs().max()).item()
+    dw.zero_(); ops.gemm(dy, x, dw, trans_a=True, b_kmajor=False, split_k=sk, accumulate=True)
+    ref = dy.float().t() @ x.float(); e_tn2 = ((dw - ref).abs().max() / ref.abs().max()).item()
+    del ref
+    bad = max(e_nt2, e_nn2) > 2e-2 or e_tn2 > 1e-3
     print(f"{name:5s} M={M} N={N} K={K}: NT {fl/t_nt/1e9:7.1f} TF ({e_nt:.1e})  NN {fl/t_nn/1e9:7.1f} TF ({e_nn:.1e})  "
-          f"TN(sk={sk}) {fl/t_tn/1e9:7.1f} TF ({e_tn:.1e})   [torch/hipBLASLt NT {fl/t_ref/1e9:7.1f} TF]", flush=True)
+          f"TN(sk={sk}) {fl/t_tn/1e9:7.1f} TF ({e_tn:.1e})   [torch/hipBLASLt NT {fl/t_ref/1e9:7.1f} TF]  after-load err {e_nt2:.1e} {e_nn2:.1e} {e_tn2:.1e}{' RACE?' if bad else ''}", flush=True)
     tot_t += t_nt + t_nn + t_tn; tot_f += 3 * fl
 print(f"layer total: {tot_t:.3f} ms per layer fwd+bwd GEMMs -> {tot_f/tot_t/1e9:.1f} TF average; x24 = {24*tot_t:.1f} ms")
