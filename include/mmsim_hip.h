@@ -187,6 +187,22 @@ int mmsim_arcface_margin(float* logits, int ld, const long long* label, int B, i
  * dcos and argmax may be NULL (evaluation). */
 int mmsim_arcface_ce(const float* cosm, int ld, const long long* label, float* loss, long long* argmax, void* dcos,
                      int B, int C, float s, float m, int easy_margin, float grad_scale, int* err_flag, void* stream);
+/* The fused head without extra passes over [B, C] (arcface.py:47-61 + nn.CrossEntropyLoss of multimodal_classifier_train.py:188):
+ * cos [B, ld] (f32) = x_hat [B, D] w_hat [ld, D]^T (bf16; rows >= C of w_hat zero), and per row lse / loss / argmax / the target's logit and
+ * margin slope from per-column-segment online-softmax statistics -- left by the cosine product's own epilogue when the pipelined
+ * 256 x 256 kernel takes the shape (B % 256 == 0, ld % 256 == 0, D % 64 == 0, >= 128 tiles), by one statistics pass otherwise --
+ * and loss_mean[0] = mean_b loss_b (NULL: skipped).  part: scratch, >= B * ceil(ld / 64) * 4 floats.  rowst [B][4] = {lse, target
+ * logit, margin slope, -}.  A label outside [0, C) sets *err_flag and contributes a zero loss.
+ * mmsim_arcface_dcos_rowfix (backward, ld % 256 == 0): ONE pass over the cosines writes dcos (bf16 [B, ld], pad zero) =
+ * dloss_dev[0] * grad_scale * dLoss_b/dcos AND the two row vectors of the weight gradient's row-fix epilogue (what
+ * mmsim_arcface_rowfix computes in a second pass): rowvec[c] = inv_w[c], rowvec[C + c] = sum_b dcos[b][c] cos[b][c].
+ * dloss_dev: the upstream gradient of the mean loss as a DEVICE scalar (NULL = 1). */
+int mmsim_arcface_fwd_fused(const void* x_hat, const void* w_hat, float* cosm, int ld, const long long* label, float* part,
+                            unsigned long long part_floats, float* rowst, float* loss_b, long long* argmax, float* loss_mean,
+                            int B, int C, int D, float s, float m, int easy_margin, int* err_flag, void* stream);
+int mmsim_arcface_dcos_rowfix(const float* cosm, int ld, const long long* label, const float* rowst, const float* dloss_dev,
+                              float grad_scale, const float* inv_w, void* dcos, float* rowvec, int B, int C, float s, float m,
+                              int easy_margin, void* stream);
 /* Backward of mmsim_arcface_margin for externally supplied dlogits (torch CrossEntropyLoss on the logits). */
 int mmsim_arcface_dlogits_to_dcos(const float* dlogits, int ld_dl, const float* cosm, int ld, const long long* label,
                                   void* dcos, int B, int C, float s, float m, int easy_margin, void* stream);

@@ -109,11 +109,41 @@ template <int CTRL> __device__ __forceinline__ float dpp_self_f(float x) {
   const int xi = __builtin_bit_cast(int, x);
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, CTRL, 0xF, 0xF, false));
 }
+// maximum / integer minimum over an aligned 16-lane row: every lane ends with the row's value (EXEC full)
+__device__ __forceinline__ float max16_dpp(float v) {
+  v = fmaxf(v, dpp_self_f<0xB1>(v)); v = fmaxf(v, dpp_self_f<0x4E>(v)); v = fmaxf(v, dpp_self_f<0x141>(v)); v = fmaxf(v, dpp_self_f<0x140>(v));
+  return v;
+}
+template <int CTRL> __device__ __forceinline__ int dpp_self_i(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int min16_dpp_i(int v) {
+  v = min(v, dpp_self_i<0xB1>(v)); v = min(v, dpp_self_i<0x4E>(v)); v = min(v, dpp_self_i<0x141>(v)); v = min(v, dpp_self_i<0x140>(v));
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_self_f<0xB1>(v)); v = fmaxf(v, dpp_self_f<0x4E>(v)); v = fmaxf(v, dpp_self_f<0x141>(v)); v = fmaxf(v, dpp_self_f<0x140>(v));
   v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
+
+// ArcFace additive angular margin (arcface.py:49-61), shared by the head kernels (head_optim.hip) and the cosine product's
+// statistics epilogue (gemm_common.h, EPI_ARCSTATS).
+struct Margin { float s, cos_m, sin_m, th, mm; int easy; };
+// Deliberate, documented deviation (DESIGN.md "Numerics"): the reference computes sqrt(1 - cos^2) without a guard
+// (arcface.py:49), which is NaN when |cos| > 1 and has an infinite gradient at |cos| = 1.  With bf16 unit vectors the
+// cosine of a sample aligned with its class row can round to 1 + 2^-8, where the fp32 reference is finite: the radicand
+// is floored at 1e-12 here, which changes nothing wherever the reference itself is finite to fp32 precision.
+__device__ __forceinline__ float margin_fwd(float c, const Margin& m, float* slope) {
+  const float sine = sqrtf(fmaxf(1.0f - c * c, 1e-12f));
+  const float phi = c * m.cos_m - sine * m.sin_m;
+  const bool take = m.easy ? (c > 0.f) : ((c - m.th) > 0.f);
+  if (slope) *slope = take ? (m.cos_m + m.sin_m * c / sine) : 1.0f;
+  return take ? phi : (m.easy ? c : c - m.mm);
+}
+
+Margin mk_margin(float s, float m, int easy);      // head_optim.hip: the constants the reference computes with python floats
+int arcface_stats_launch(const float* cosm, int ld, const long long* label, float* part, int B, int C, int nseg, Margin m, hipStream_t s);
+int arcface_combine_launch(const float* part, int nseg, const float* cosm, int ld, const long long* label, float* rowst, float* loss_b,
+                           long long* argmax, float* loss_mean, int B, int C, Margin m, int* err, hipStream_t s);
 
 // exact-erf GELU and its derivative (HF "gelu", modeling_bert.py:334-337)
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

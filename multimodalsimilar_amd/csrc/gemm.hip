@@ -16,6 +16,7 @@
 // are neighbours (shared A panel in that XCD's L2).
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 #define BM 128
 #define BN 128
@@ -366,7 +367,8 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
                      int ldb, void* C, int ldc, int c_is_f32, const float* bias, int epilogue,
                      const void* aux_in, void* aux_out, int ld_aux, float alpha, int split_k,
                      int accumulate, int xf_operand, const float* xf_scale, const float* xf_shift, const float* xf_gate,
-                     int xf_hw, void* stream, float* stats = nullptr, float* colsum = nullptr, int fmt = 0) {
+                     int xf_hw, void* stream, float* stats = nullptr, float* colsum = nullptr, int fmt = 0,
+                     const long long* arc_label = nullptr, float* arc_part = nullptr, int arc_C = 0, const Margin* arc_m = nullptr) {
   MMSIM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: M, N, K must be positive");
   MMSIM_REQUIRE(fmt >= 0 && fmt <= 2, "gemm: fmt must be 0 (bf16), 1 (fp16 operands) or 2 (fp16 B converted to bf16)");
   MMSIM_REQUIRE(fmt != 1 || (!trans_a && b_kmajor && xf_operand != 2 && split_k == 1 && (c_is_f32 || (epilogue == EPI_NONE && !bias))),
@@ -377,7 +379,7 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   MMSIM_REQUIRE((ldc % 4) == 0, "gemm: ldc must be a multiple of 4");
   MMSIM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
                 "gemm: operands must be 16-byte aligned");
-  MMSIM_REQUIRE(epilogue >= 0 && epilogue <= 7, "gemm: unknown epilogue");
+  MMSIM_REQUIRE((epilogue >= 0 && epilogue <= 7) || (epilogue == EPI_ARCSTATS && arc_label && arc_part && arc_m), "gemm: unknown epilogue");
   MMSIM_REQUIRE(epilogue != EPI_ROWFIX || (c_is_f32 && split_k == 1 && bias && aux_in),
                 "gemm: the row-fix epilogue needs an f32 output, no split-K, the [2][M] row vectors in bias and aux_in");
   MMSIM_REQUIRE(!(epilogue == EPI_GELU || epilogue == EPI_GELU_DGELU) || aux_out, "gemm: GELU epilogues need aux_out (pre-activation / gelu')");
@@ -399,6 +401,8 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   p.xf_scale = xf_scale; p.xf_shift = xf_shift; p.xf_gate = xf_gate; p.xf_hw = xf_hw > 0 ? xf_hw : 1; p.xf_dhw = make_fastdiv(p.xf_hw);
   p.xf_C = (xf_operand == 1) ? K : N;
   p.stats = stats; p.band = 1; p.colsum = colsum; p.fmt = fmt;
+  p.arc_label = arc_label; p.arc_part = arc_part; p.arc_C = arc_C;
+  if (arc_m) p.arc_m = *arc_m; else memset(&p.arc_m, 0, sizeof(p.arc_m));
 #ifdef MMSIM_ABLATE     // ablation object only (tools/bench_gemm_abl.py); the product library never reads this variable
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MMSIM_GEMM_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
 #else
@@ -413,6 +417,8 @@ static int gemm_impl(int trans_a, int b_kmajor, int M, int N, int K, const void*
   dim3 grid(p.tiles_m * p.tiles_n * splits), block(256);
   const size_t lds = 2 * STAGE_BYTES;
   hipStream_t s = (hipStream_t)stream;
+  MMSIM_REQUIRE(epilogue != EPI_ARCSTATS || (xf_operand == 0 && !stats && fmt == 0 && !force_generic() && gemm_fast_eligible(p, splits)),
+                "gemm: the softmax-statistics epilogue needs the pipelined 256 x 256 forward kernel");
   MMSIM_REQUIRE(!colsum || (trans_a && !b_kmajor && xf_operand == 0 && !stats && fmt == 0 && !force_generic() && gemm_fast_eligible(p, splits)),
                 "gemm: the fused column sum needs the pipelined weight-gradient kernel");
   if (xf_operand == 0 && !stats && fmt == 0 && !force_generic() && (gemm_fast_eligible(p, splits) || gemm_fast_rowfix(p, splits, trans_a, b_kmajor))) {
@@ -525,6 +531,34 @@ extern "C" int mmsim_gemm_bf16(int trans_a, int b_kmajor, int M, int N, int K, c
                                int accumulate, void* stream) {
   return gemm_impl(trans_a, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, c_is_f32, bias, epilogue, aux_in, aux_out, ld_aux,
                    alpha, split_k, accumulate, 0, nullptr, nullptr, nullptr, 1, stream);
+}
+
+// The fused ArcFace forward (head.py forward_loss; arcface.py:47-61 + nn.CrossEntropyLoss, multimodal_classifier_train.py:188):
+//   cos[B, ld] = x_hat w_hat^T  (bf16 MFMA, f32 out; w_hat has ld rows, those >= C zero),
+//   per row: lse, loss, argmax, the target's logit and margin slope -- from per-segment online-softmax statistics that the cosine
+//   product's own epilogue leaves (pipelined 256 x 256 kernel: B % 256 == 0, ld % 256 == 0, D % 64 == 0, >= 128 tiles) or, for
+//   other shapes, one pass of arcface_stats_kernel over the cosines; then the mean loss.
+// part: scratch of >= B * ceil(ld / 64) * 4 floats.  rowst [B][4] = {lse, target logit, margin slope, -} is what
+// mmsim_arcface_dcos_rowfix reads in the backward.  No logits / softmax / one-hot tensor exists; the cosines are written once here
+// and read once in the backward.
+bool gemm_fast_arcstats(const GemmParams& p);
+extern "C" int mmsim_arcface_fwd_fused(const void* x_hat, const void* w_hat, float* cosm, int ld, const long long* label, float* part,
+                                       unsigned long long part_floats, float* rowst, float* loss_b, long long* argmax, float* loss_mean,
+                                       int B, int C, int D, float s, float m, int easy_margin, int* err_flag, void* stream) {
+  MMSIM_REQUIRE(x_hat && w_hat && cosm && label && part && rowst && loss_b && err_flag, "arcface_fwd_fused: null operand");
+  MMSIM_REQUIRE(B > 0 && C > 0 && D > 0 && ld >= C && (ld % 8) == 0 && (D % 8) == 0, "arcface_fwd_fused: ld >= C, ld and D multiples of 8");
+  const Margin mg = mk_margin(s, m, easy_margin);
+  GemmParams probe;
+  memset(&probe, 0, sizeof(probe));
+  probe.M = B; probe.N = ld; probe.K = D; probe.ldc = ld; probe.c_f32 = 1; probe.epi = EPI_ARCSTATS; probe.k_per_split = ((D + BK - 1) / BK) * BK;
+  const bool fused = !force_generic() && !g_group.active && gemm_fast_arcstats(probe);
+  const int nseg = fused ? ld / 64 : (C + 1023) / 1024;
+  MMSIM_REQUIRE(part_floats >= (unsigned long long)B * nseg * 4, "arcface_fwd_fused: statistics scratch too small (B * ceil(ld / 64) * 4 floats)");
+  int rc = gemm_impl(0, 1, B, ld, D, x_hat, D, w_hat, D, cosm, ld, 1, nullptr, fused ? EPI_ARCSTATS : EPI_NONE, nullptr, nullptr, 0, 1.0f, 1, 0, 0,
+                     nullptr, nullptr, nullptr, 1, stream, nullptr, nullptr, 0, fused ? label : nullptr, fused ? part : nullptr, C, fused ? &mg : nullptr);
+  if (rc) return rc;
+  if (!fused) { rc = arcface_stats_launch(cosm, ld, label, part, B, C, nseg, mg, (hipStream_t)stream); if (rc) return rc; }
+  return arcface_combine_launch(part, nseg, cosm, ld, label, rowst, loss_b, argmax, loss_mean, B, C, mg, err_flag, (hipStream_t)stream);
 }
 
 // The same product with an explicit element format (GemmParams::fmt): 1 = fp16 A, B (and C unless f32), forward layout only;

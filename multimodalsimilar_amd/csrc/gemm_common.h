@@ -25,6 +25,11 @@ struct GemmParams {
   //   2  bf16 A, fp16 B converted to bf16 while it is staged, f32 C (image-tower weight gradients: A = the bf16 gradient, B = the
   //      fp16 activation)
   int fmt;
+  // EPI_ARCSTATS (forward layout, f32 C = the cosines [B, ldc]; gemm_pp64_kernel<false, true, 256> only): besides storing the cosines the
+  // epilogue leaves, per output row and per 64-column segment, the online-softmax statistics of the scaled margin logits
+  // (arcface.py:49-61 + the cross-entropy's log-sum-exp): arc_part[(m * N / 64 + col / 64)] = {max, sum exp(z - max), argmax (int bits), 0}.
+  // Columns >= arc_C (the zero pad rows of w_hat) are left out; the margin is applied at column arc_label[m].
+  const long long* arc_label; float* arc_part; int arc_C; Margin arc_m;
   int dbg;   // ablation object only (-DMMSIM_ABLATE): 1 no DMA, 4 no MFMA, 8 no epilogue; the product build ignores it
 };
 
@@ -33,7 +38,7 @@ struct GemmParams {
 // EPI_GELU_DGELU / EPI_MUL: the GELU pair the text tower uses.  Forward: out = gelu(pre) and aux_out = gelu'(pre) (the erf is
 // shared, one more exp) -- so the dgrad epilogue is ONE multiply per element by a prefetched operand instead of erf + exp on
 // the GEMM's critical path (EPI_MUL_GELU_GRAD recomputes gelu' from the stored pre-activation: ~7 us of VALU per 256x256 tile).
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_MUL_GELU_GRAD = 2, EPI_ADD = 3, EPI_TANH = 4, EPI_ROWFIX = 5, EPI_GELU_DGELU = 6, EPI_MUL = 7 };
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_MUL_GELU_GRAD = 2, EPI_ADD = 3, EPI_TANH = 4, EPI_ROWFIX = 5, EPI_GELU_DGELU = 6, EPI_MUL = 7, EPI_ARCSTATS = 8 };
 
 // gelu(x) = x Phi(x) and gelu'(x) = Phi(x) + x phi(x) from ONE exponential: Phi through the rational-times-Gaussian form of erfc
 // (Abramowitz & Stegun 7.1.26: |error| <= 1.5e-7 on erf, i.e. fp32-level -- libm's erff is itself ~1e-7), whose Gaussian factor
@@ -150,6 +155,30 @@ __device__ __forceinline__ void fast_epilogue(const GemmParams& p, f4 (&acc)[4][
       const float rs = p.bias[m], rr = p.bias[(size_t)p.M + m];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = rs * (v[e] - bf2f(x[e]) * rr);
+    } else if (EPI == EPI_ARCSTATS) {
+      // v = four cosines of row m; the row's 64 columns of this wave sit in the 16 lanes of one DPP row (full tiles: EXEC is full)
+      const long long y = p.arc_label[m];
+      float z[4], mx = -3.0e38f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = n + e;
+        z[e] = col < p.arc_C ? ((long long)col == y ? margin_fwd(v[e], p.arc_m, nullptr) : v[e]) * p.arc_m.s : -3.0e38f;
+        mx = fmaxf(mx, z[e]);
+      }
+      mx = max16_dpp(mx);
+      float sm = 0.f;
+      int am = 0x7fffffff;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sm += z[e] > -1.0e38f ? __expf(z[e] - mx) : 0.f;
+        if (z[e] == mx && am == 0x7fffffff) am = n + e;            // lowest index among equal maxima
+      }
+      sm = sum16_dpp(sm);
+      am = min16_dpp_i(am);
+      if ((lane & 15) == 0) {
+        const f4 o = {mx, sm, __int_as_float(am), 0.f};
+        *reinterpret_cast<f4*>(p.arc_part + ((size_t)m * (size_t)(p.N >> 6) + (size_t)(col0 >> 6)) * 4) = o;
+      }
     }
     if (CMODE == 0) {
       bf4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};

@@ -218,9 +218,16 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(GemmParams p) {
 // of slice u, which ends at the barrier that opens the leading group's odd load phase.  RAW: slice u + 1 (A_{u+1} from the even
 // phases, B_{u+1} from the odd phases of slice u - 1; A_1 | B_1 from the prologue) is waited for at the end of the odd LOAD phase of
 // slice u, where exactly A_{u+2} and the first half of B_{u+2} are younger.
+// Measured (r04, tools/bench_gemm.py, alternating builds on one box, M = 32 768): data-gradient layout +3.6 / +1.5 / +6 / -0.5 % on the
+// qkv / o / ffn1 / ffn2 shapes (1 074 vs 1 041, 1 102 vs 1 086, 1 251-1 259 vs 1 173-1 197, 1 024-1 034 vs 1 025-1 058 TFLOP/s); forward layout
+// -2 ... 0 % (qkv 1 055 vs 1 064-1 091); weight-gradient layout (which already splits its B pieces, PP64_B_SPLIT) +-3 %, 0 on average.  So the
+// issue-cycle model above explains only part of a slice: the load path (64 KiB of LDS-DMA writes + 192 KiB of fragment reads per slice
+// through one LDS) is within 20 % of the matrix path however its instructions are placed.  On for the data-gradient layout only
+// (PP64_BAL_LAYOUT); 2 = every layout, 0 = off.
 #ifndef PP64_BAL
 #define PP64_BAL 1
 #endif
+#define PP64_BAL_LAYOUT(TA, TBK) (PP64_BAL == 2 || (PP64_BAL == 1 && !(TA) && !(TBK)))
 #ifndef PP64_B_KEEP
 #define PP64_B_KEEP 2             // pieces (of four at BN = 256) that stay in the load phase; the others follow MFMA rows 0, 1, ...
                                   // (1 measured the same as 2, 0 about 1 % below them on the weight-gradient products)
@@ -325,22 +332,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
   for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
   const bool dma_on = !(PP64_DBG(p) & 1);
   constexpr int B_LPU = BN * 128 / (8 * 1024);             // LDS-DMA pieces per wave per B unit (4 or 2)
+  constexpr bool BAL = PP64_BAL_LAYOUT(TA, TB_KMAJOR);
   if (dma_on) {
     dma_tile<TA, GBM>(gA, glda, m0, kbeg, smem, wave, lane);
     dma_tile<!TB_KMAJOR, BN>(gB, gldb, n0, kbeg, smem + B_OFF, wave, lane);
     if (ns > 1) dma_tile<TA, GBM>(gA, glda, m0, kbeg + 64, smem + A_UNIT, wave, lane);
-#if PP64_BAL
-    if (ns > 1) dma_tile<!TB_KMAJOR, BN>(gB, gldb, n0, kbeg + 64, smem + B_OFF + B_UNIT, wave, lane);
-#endif
+    if (BAL && ns > 1) dma_tile<!TB_KMAJOR, BN>(gB, gldb, n0, kbeg + 64, smem + B_OFF + B_UNIT, wave, lane);
   }
-#if PP64_BAL
-  if (ns > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LPU + B_LPU) : "memory");
-#else
-  if (ns > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LPU) : "memory");
-#endif
+  if (ns > 1) {
+    if constexpr (BAL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LPU + B_LPU) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LPU) : "memory");
+  }
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (grp == 1) __builtin_amdgcn_s_barrier();            // the anti-phase offset
-  bf8 af[MT], bfr[PP64_BAL ? 8 : 4];
+  bf8 af[MT], bfr[8];                                    // the balanced schedule holds the B fragments of both k-halves
   int sa = 0;                                            // A slot of slice u (u mod 3)
 #define PP64_READ(KS)                                                                                    \
   {                                                                                                      \
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
   }
   const size_t astep = TA ? (size_t)64 * glda : (size_t)64;
   const bf16* bsrc[B_LPU];                                 // the same for B: piece i of slice 1 (balanced schedule: 2) first
-  constexpr int BS0 = PP64_BAL ? 128 : 64;
+  constexpr int BS0 = BAL ? 128 : 64;
   {
 #pragma unroll
     for (int i = 0; i < B_LPU; ++i) {
@@ -432,7 +437,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     }                                                                                                    \
   }                                                                                                      \
   __builtin_amdgcn_sched_barrier(0);
-#if PP64_BAL
 #define PP64_COLSUM()                                                                                    \
     if constexpr (COLSUM_OK) {                                                                           \
       if (do_colsum) {                                                                                   \
@@ -464,6 +468,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     PP64_COLSUM()                                                                                        \
   }                                                                                                      \
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (BAL) {
   for (int u = 0; u < ns; ++u) {
     const bool donext = u + 2 < ns && dma_on;              // slice u + 2 exists: this slice issues A_{u+2} and B_{u+2}
     int sn = sa + 2; if (sn >= 3) sn -= 3;
@@ -515,9 +520,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     PP64_MFMA_BAL(4, donext, B_LPU / 2, B_LPU, bsrc, bstep, bdst, B_LPU)
     sa = sa + 1; if (sa >= 3) sa = 0;
   }
-#undef PP64_MFMA_BAL
-#undef PP64_COLSUM
-#else
+  } else {
   for (int u = 0; u < ns; ++u) {
     // ---- even step: k-half 0 of slice u
     __builtin_amdgcn_s_barrier();
@@ -601,7 +604,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
 #endif
     sa = sa + 1; if (sa >= 3) sa = 0;
   }
-#endif
+  }
+#undef PP64_MFMA_BAL
+#undef PP64_COLSUM
 #undef PP64_MFMA_A
 #undef PP64_MFMA_B
 #undef PP64_MFMA_X
@@ -663,6 +668,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
     }
     else if (p.accum) fast_epilogue<EPI_NONE, 2>(p, a4, row0, col0, lane, fs, stg);
     else if (p.epi == EPI_TANH) fast_epilogue<EPI_TANH, 1>(p, a4, row0, col0, lane, fs, stg);
+    else if (!TA && TB_KMAJOR && BN == 256 && !GRP && p.epi == EPI_ARCSTATS) fast_epilogue<EPI_ARCSTATS, 1>(p, a4, row0, col0, lane, fs, stg);
     else fast_epilogue<EPI_NONE, 1>(p, a4, row0, col0, lane, fs, stg);
   };
   epi_half(*reinterpret_cast<f4 (*)[4][4]>(&acc[0][0]), 0);
@@ -689,7 +695,11 @@ static bool fast128_eligible(const GemmParams& p, int splits) {
 }
 
 bool gemm_fast_rowfix(const GemmParams& p, int splits, int trans_a, int b_kmajor) { return trans_a && !b_kmajor && rowfix_eligible(p, splits); }
+bool gemm_fast_arcstats(const GemmParams& p) {        // the cosine product with the softmax-statistics epilogue: forward layout, f32 output, 256 x 256 tiles
+  return p.epi == EPI_ARCSTATS && p.c_f32 && !p.atomic && !p.accum && (p.ldc % 4) == 0 && pipe_eligible(p, 1, 256);
+}
 bool gemm_fast_eligible(const GemmParams& p, int splits) {
+  if (p.epi == EPI_ARCSTATS) return splits == 1 && gemm_fast_arcstats(p);
   if (p.c_f32 && !(p.epi == EPI_NONE || p.epi == EPI_TANH)) return false;   // f32 outputs: plain / tanh only (row-fix: gemm_fast_rowfix)
   if ((p.ldc % 4) || (p.ld_aux % 4)) return false;
   if ((long long)p.k_per_split * splits < p.K) return false;
@@ -730,7 +740,7 @@ static void launch_pipe(GemmParams p, int trans_a, int b_kmajor, int splits, hip
 }
 
 void gemm_fast_launch(GemmParams p, int trans_a, int b_kmajor, int splits, hipStream_t s) {
-  if (p.colsum || (p.epi == EPI_ROWFIX && p.c_f32)) { launch_pipe<256>(p, trans_a, b_kmajor, splits, s); return; }      // only this kernel sums the columns (host checked the shape)
+  if (p.colsum || (p.epi == EPI_ROWFIX && p.c_f32) || p.epi == EPI_ARCSTATS) { launch_pipe<256>(p, trans_a, b_kmajor, splits, s); return; }      // only this kernel sums the columns (host checked the shape)
   const int pref = tile_pref();
   // wgrad-shaped products (A transposed: few output tiles, long reduction, split-K) take the narrower tile: more tiles
   // per split and half the atomic traffic per block; everything else prefers 256x256 (twice the flop per staged byte)

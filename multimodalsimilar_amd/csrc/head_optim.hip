@@ -5,20 +5,6 @@
 //   adamw               torch.optim.AdamW semantics over a flat fp32 buffer, also refreshes the bf16 shadow
 #include "common.h"
 
-struct Margin { float s, cos_m, sin_m, th, mm; int easy; };
-
-// Deliberate, documented deviation (DESIGN.md "Numerics"): the reference computes sqrt(1 - cos^2) without a guard
-// (arcface.py:49), which is NaN when |cos| > 1 and has an infinite gradient at |cos| = 1.  With bf16 unit vectors the
-// cosine of a sample aligned with its class row can round to 1 + 2^-8, where the fp32 reference is finite: the radicand
-// is floored at 1e-12 here, which changes nothing wherever the reference itself is finite to fp32 precision.
-__device__ __forceinline__ float margin_fwd(float c, const Margin& m, float* slope) {
-  const float sine = sqrtf(fmaxf(1.0f - c * c, 1e-12f));
-  const float phi = c * m.cos_m - sine * m.sin_m;
-  const bool take = m.easy ? (c > 0.f) : ((c - m.th) > 0.f);
-  if (slope) *slope = take ? (m.cos_m + m.sin_m * c / sine) : 1.0f;
-  return take ? phi : (m.easy ? c : c - m.mm);
-}
-
 __global__ __launch_bounds__(256) void arcface_margin_kernel(float* z, int ld, const int64_t* label, int B, int C, Margin m,
                                                              int* err) {
   const int b = blockIdx.y;
@@ -344,8 +330,140 @@ __global__ __launch_bounds__(256) void adamw_rows_l2norm_kernel(float* p, const 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The fused head (forward_loss): the cosine product's epilogue (EPI_ARCSTATS, gemm_common.h) or -- for shapes the pipelined GEMM
+// does not take -- arcface_stats_kernel leaves per (row, column segment) {max, sum exp(z - max), argmax, -} of the scaled margin
+// logits z = s (c == y ? margin(cos) : cos)   (arcface.py:49-61).  arcface_combine_kernel folds a row's segments into its
+// log-sum-exp, loss, argmax and the target's logit / margin slope; arcface_mean_kernel is CrossEntropyLoss's mean
+// (multimodal_classifier_train.py:188).  Backward: arcface_dcos_rowfix_kernel.
+__global__ __launch_bounds__(256) void arcface_stats_kernel(const float* __restrict__ cosm, int ld, const int64_t* __restrict__ label,
+                                                            float* __restrict__ part, int C, int nseg, Margin m) {
+  __shared__ float sh_f[8];
+  __shared__ int sh_i[4];
+  const int b = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
+  const int64_t y = label[b];
+  const float* row = cosm + (size_t)b * ld;
+  const int c = seg * 1024 + tid * 4;
+  float mx = -3.0e38f, sm = 0.f;
+  int am = 0x7fffffff;
+  if (c < C) {
+    const float4 v = *reinterpret_cast<const float4*>(row + c);
+    const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (c + e < C) {
+        const float z = ((int64_t)(c + e) == y ? margin_fwd(a[e], m, nullptr) : a[e]) * m.s;
+        if (z > mx) { sm = sm * __expf(mx - z) + 1.0f; mx = z; am = c + e; }
+        else sm += __expf(z - mx);
+      }
+    }
+  }
+  block_reduce_ms(mx, sm, am, sh_f, sh_i);
+  if (tid == 0) {
+    float* o = part + ((size_t)b * nseg + seg) * 4;
+    o[0] = mx; o[1] = sm; o[2] = __int_as_float(am); o[3] = 0.f;
+  }
+}
+
+// one block per row: part [B][nseg][4] -> lse, loss, argmax, target logit zt and margin slope (kept for the backward)
+__global__ __launch_bounds__(256) void arcface_combine_kernel(const float* __restrict__ part, int nseg, const float* __restrict__ cosm, int ld,
+                                                              const int64_t* __restrict__ label, float* __restrict__ rowst, float* __restrict__ loss,
+                                                              long long* __restrict__ argmax, int C, Margin m, int* err) {
+  __shared__ float sh_f[8];
+  __shared__ int sh_i[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t y = label[b];
+  const bool bad = (y < 0 || y >= C);
+  if (tid == 0 && bad) atomicExch(err, 1);
+  float mx = -3.0e38f, sm = 0.f;
+  int am = 0x7fffffff;
+  const float4* pr = reinterpret_cast<const float4*>(part) + (size_t)b * nseg;
+  for (int i = tid; i < nseg; i += 256) {
+    const float4 q = pr[i];
+    const int qa = __float_as_int(q.z);
+    if (q.y > 0.f) {                      // a segment with at least one valid column
+      const float nm = fmaxf(mx, q.x);
+      sm = sm * __expf(mx - nm) + q.y * __expf(q.x - nm);
+      if (q.x > mx || (q.x == mx && qa < am)) am = qa;
+      mx = nm;
+    }
+  }
+  block_reduce_ms(mx, sm, am, sh_f, sh_i);
+  if (tid == 0) {
+    const float lse = mx + __logf(sm);
+    float zt = 0.f, slope = 1.f;
+    if (!bad) zt = margin_fwd(cosm[(size_t)b * ld + y], m, &slope) * m.s;
+    float* o = rowst + (size_t)b * 4;
+    o[0] = lse; o[1] = zt; o[2] = slope; o[3] = 0.f;
+    loss[b] = bad ? 0.f : (lse - zt);
+    if (argmax) argmax[b] = am;
+  }
+}
+
+__global__ __launch_bounds__(256) void arcface_mean_kernel(const float* __restrict__ loss_b, int B, float* __restrict__ out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) a += loss_b[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)B;
+}
+
+// Backward of the fused head in ONE pass over the cosines: dcos[b][c] = (dloss / B) s (target ? slope : 1) (exp(z - lse[b]) - [target])
+// (bf16 [B, ld], pad columns zero) AND the two row vectors of the weight gradient's row-fix epilogue, rowvec[c] = 1 / ||w_c|| and
+// rowvec[C + c] = sum_b dcos[b][c] cos[b][c] (= w_hat_c . dW_hat_c), which used to be a second pass over both [B, C] matrices
+// (arcface_rowfix_kernel).  A block owns 256 columns; wave w walks rows w, w + 4, ... with four rows of loads in flight; the
+// column sums use the ROUNDED dcos (what the dW product reads) and are added over the four waves in a fixed order.
+// dloss_dev: the upstream gradient of the mean loss as a DEVICE scalar (autograd hands it over as a tensor; no host sync).
+__global__ __launch_bounds__(256) void arcface_dcos_rowfix_kernel(const float* __restrict__ cosm, int ld, const int64_t* __restrict__ label,
+                                                                  const float* __restrict__ rowst, const float* __restrict__ dloss_dev,
+                                                                  float gscale, const float* __restrict__ inv_w, bf16* __restrict__ dcos,
+                                                                  float* __restrict__ rowvec, int B, int C, Margin m) {
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const float gs = (dloss_dev ? dloss_dev[0] : 1.0f) * gscale * m.s;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  auto one = [&](int b, const float4& v) __attribute__((always_inline)) {
+    const int64_t y = label[b];
+    const float4 st = *reinterpret_cast<const float4*>(rowst + (size_t)b * 4);      // lse, zt, slope
+    const float a[4] = {v.x, v.y, v.z, v.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool tgt = (int64_t)(c + e) == y;
+      const float z = tgt ? st.y : a[e] * m.s;
+      const float g = (__expf(z - st.x) - (tgt ? 1.0f : 0.0f)) * gs * (tgt ? st.z : 1.0f);
+      o[e] = (c + e < C) ? g : 0.f;
+    }
+    const bf4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+    *reinterpret_cast<bf4*>(dcos + (size_t)b * ld + c) = ob;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += bf2f(ob[e]) * a[e];
+  };
+  int b = wv;
+  for (; b + 12 < B; b += 16) {
+    const float4 v0 = *reinterpret_cast<const float4*>(cosm + (size_t)b * ld + c);
+    const float4 v1 = *reinterpret_cast<const float4*>(cosm + (size_t)(b + 4) * ld + c);
+    const float4 v2 = *reinterpret_cast<const float4*>(cosm + (size_t)(b + 8) * ld + c);
+    const float4 v3 = *reinterpret_cast<const float4*>(cosm + (size_t)(b + 12) * ld + c);
+    one(b, v0); one(b + 4, v1); one(b + 8, v2); one(b + 12, v3);
+  }
+  for (; b < B; b += 4) one(b, *reinterpret_cast<const float4*>(cosm + (size_t)b * ld + c));
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wv][lane * 4 + e] = acc[e];
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < C) {
+    rowvec[cc] = inv_w[cc];
+    rowvec[(size_t)C + cc] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
 // ================================================================= C-ABI
-static Margin mk_margin(float s, float m, int easy) {
+Margin mk_margin(float s, float m, int easy) {
   Margin r;
   r.s = s; r.cos_m = cosf(m); r.sin_m = sinf(m);
   r.th = cosf(3.14159265358979323846f - m); r.mm = sinf(3.14159265358979323846f - m) * m; r.easy = easy;
@@ -363,6 +481,28 @@ extern "C" int mmsim_arcface_margin(float* logits, int ld, const long long* labe
   hipLaunchKernelGGL(arcface_margin_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, logits, ld,
                      (const int64_t*)label, B, C, mk_margin(s, m, easy_margin), err_flag);
   return mmsim_check_launch("arcface_margin");
+}
+
+// launchers used by mmsim_arcface_fwd_fused (gemm.hip: it owns the cosine product)
+int arcface_stats_launch(const float* cosm, int ld, const long long* label, float* part, int B, int C, int nseg, Margin m, hipStream_t s) {
+  hipLaunchKernelGGL(arcface_stats_kernel, dim3(nseg, B), dim3(256), 0, s, cosm, ld, (const int64_t*)label, part, C, nseg, m);
+  return mmsim_check_launch("arcface_stats");
+}
+int arcface_combine_launch(const float* part, int nseg, const float* cosm, int ld, const long long* label, float* rowst, float* loss_b,
+                           long long* argmax, float* loss_mean, int B, int C, Margin m, int* err, hipStream_t s) {
+  hipLaunchKernelGGL(arcface_combine_kernel, dim3(B), dim3(256), 0, s, part, nseg, cosm, ld, (const int64_t*)label, rowst, loss_b, argmax, C, m, err);
+  if (loss_mean) hipLaunchKernelGGL(arcface_mean_kernel, dim3(1), dim3(256), 0, s, loss_b, B, loss_mean);
+  return mmsim_check_launch("arcface_combine");
+}
+
+extern "C" int mmsim_arcface_dcos_rowfix(const float* cosm, int ld, const long long* label, const float* rowst, const float* dloss_dev,
+                                         float grad_scale, const float* inv_w, void* dcos, float* rowvec, int B, int C, float s, float m,
+                                         int easy_margin, void* stream) {
+  MMSIM_REQUIRE(cosm && label && rowst && inv_w && dcos && rowvec && B > 0 && C > 0, "arcface_dcos_rowfix: bad arguments");
+  MMSIM_REQUIRE(ld % 256 == 0 && ld >= C, "arcface_dcos_rowfix: ld must be a multiple of 256 and >= C (pad the class dimension)");
+  hipLaunchKernelGGL(arcface_dcos_rowfix_kernel, dim3(ld / 256), dim3(256), 0, (hipStream_t)stream, cosm, ld, (const int64_t*)label, rowst,
+                     dloss_dev, grad_scale, inv_w, (bf16*)dcos, rowvec, B, C, mk_margin(s, m, easy_margin));
+  return mmsim_check_launch("arcface_dcos_rowfix");
 }
 
 extern "C" int mmsim_arcface_ce(const float* cosm, int ld, const long long* label, float* loss, long long* argmax,

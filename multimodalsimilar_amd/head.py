@@ -2,8 +2,10 @@
 
 ArcMarginProduct mirrors /root/reference/arcface.py:17-67 (same constructor, attributes, forward /
 forward_test / update_m) and adds ``forward_loss`` -- the fused path the training entry point uses:
-normalise -> bf16 MFMA cosine GEMM -> margin + scaled cross-entropy + argmax + dcos in one pass over the
-cosines (no logits / softmax / one-hot tensors), then the two backward GEMMs.  The weight matrix is the big operand
+normalise -> bf16 MFMA cosine GEMM whose EPILOGUE leaves per-segment online-softmax statistics of the scaled margin logits
+(mmsim_arcface_fwd_fused: no logits / softmax / one-hot tensors, no separate pass over the cosines) -> one combine per row (log-sum-exp,
+loss, argmax) + the mean; backward: ONE pass over the cosines writes dcos (the upstream gradient read from device memory) and the
+row vectors of the weight gradient's normalisation backward (mmsim_arcface_dcos_rowfix), then the two backward GEMMs.  The weight matrix is the big operand
 ([classes, D], 1.1 GB fp32 at 100 000 x 2816), so nothing passes over it on its own: F.normalize(weight) comes out of the
 AdamW launch (or is reused while the weights are static) and its backward is the dW product's epilogue.
 """
@@ -116,8 +118,9 @@ class ArcMarginProduct(nn.Module):
         return t
 
     # ---- kernels
-    def _cosines(self, x):
-        """x [B,D] f32 -> (cos f32 [B, ldc] view [:, :C], saved state)."""
+    def _cosines(self, x, product=True):
+        """x [B,D] f32 -> (cos f32 [B, ldc] view [:, :C], saved state).  product=False: everything but the cosine product itself (the
+        fused forward runs it with the statistics epilogue)."""
         if not x.is_cuda:
             raise MmsimError("ArcMarginProduct: inputs must be on the GPU; the HIP path has no CPU fallback")
         if x.dim() != 2 or x.shape[1] != self.in_feature:
@@ -137,7 +140,8 @@ class ArcMarginProduct(nn.Module):
             ops.l2norm_fwd(self.weight.detach(), None, wh, 0, inv_w)                 # F.normalize(self.weight)
             self._wh_key = key
         ops.l2norm_fwd(x, None, xh, 0, inv_x)                                        # F.normalize(x)
-        ops.gemm(xh, whp, cos)                                                       # F.linear  (arcface.py:47); pad columns = 0
+        if product:
+            ops.gemm(xh, whp, cos)                                                   # F.linear  (arcface.py:47); pad columns = 0
         return cos, dict(x=x, xh=xh, wh=wh, whp=whp, inv_x=inv_x, inv_w=inv_w, B=B, ldc=ldc, gen=self._gen)
 
     def _check_gen(self, st):
@@ -147,7 +151,7 @@ class ArcMarginProduct(nn.Module):
             raise MmsimError("ArcMarginProduct: backward of a forward whose scratch buffers were overwritten by a later call; "
                              "run backward before the next forward of this head")
 
-    def _backward_from_dcos(self, st, dcos, cos=None):
+    def _backward_from_dcos(self, st, dcos, cos=None, rowvec=None):
         """dcos bf16 [B, ldc] (pad zero) -> dx f32 [B,D]; accumulates into weight.grad.  With the cosines at hand the backward of
         F.normalize(self.weight) is folded into the dcos^T x_hat product's epilogue (no fp32 dW_hat round trip, no second pass
         over W): w_hat . dW_hat = sum_b dcos cos, so both row vectors of the correction are known before the product runs."""
@@ -164,8 +168,9 @@ class ArcMarginProduct(nn.Module):
         # this product writes every element of the head's gradient buffer: after a lazy zero_grad it overwrites (no fill, no read)
         acc = not self._flat.take_zero_pending()
         if cos is not None and _FUSED_DW:
-            rowvec = self._buf("rowvec", (2, C), torch.float32)
-            ops.lib.arcface_rowfix(dcos.data_ptr(), cos.data_ptr(), ldc, st["inv_w"].data_ptr(), rowvec.data_ptr(), B, C, ops._stream())
+            if rowvec is None:            # (the fused loss path's dcos pass has already left the two row vectors)
+                rowvec = self._buf("rowvec", (2, C), torch.float32)
+                ops.lib.arcface_rowfix(dcos.data_ptr(), cos.data_ptr(), ldc, st["inv_w"].data_ptr(), rowvec.data_ptr(), B, C, ops._stream())
             ops.gemm(dcos[:, :C], st["xh"], self._flat.gview("weight").view(C, D), trans_a=True, b_kmajor=False, bias=rowvec,
                      epilogue=ops.EPI_ROWFIX, aux_in=st["wh"], accumulate=acc)
         else:
@@ -235,29 +240,47 @@ class _ArcLogitsFn(torch.autograd.Function):
 
 
 class _ArcLossFn(torch.autograd.Function):
+    """loss = CrossEntropyLoss(ArcMarginProduct(x, label), label)  (arcface.py:45-63 + multimodal_classifier_train.py:188) and the argmax
+    of the margin logits (:191), without a [B, C] tensor other than the cosines: written once by the cosine product (whose epilogue
+    also leaves the softmax statistics), read once by the backward."""
+
     @staticmethod
     def forward(ctx, x, weight, mod, label):
-        cos, st = mod._cosines(x)
-        B, C = st["B"], mod.out_feature
+        cos, st = mod._cosines(x, product=False)
+        B, C, D, ldc = st["B"], mod.out_feature, mod.in_feature, st["ldc"]
         label = label.contiguous()
-        loss_b = torch.empty(B, dtype=torch.float32, device=x.device)
-        argmax = torch.empty(B, dtype=torch.int64, device=x.device)
-        need_grad = x.requires_grad or weight.requires_grad
-        dcos = mod._buf("dcos", (B, st["ldc"]), torch.bfloat16) if need_grad else None
-        ops.lib.arcface_ce(cos.data_ptr(), st["ldc"], label.data_ptr(), loss_b.data_ptr(), argmax.data_ptr(),
-                           None if dcos is None else dcos.data_ptr(), B, C, mod.s, mod.m, int(mod.easy_margin),
-                           1.0 / B, mod._err_flag().data_ptr(), ops._stream())
-        ctx.mod, ctx.st, ctx.dcos, ctx.cos = mod, st, dcos, cos       # cos: the module's scratch, intact until the next forward
+        dev = x.device
+        loss_b = torch.empty(B, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        argmax = torch.empty(B, dtype=torch.int64, device=dev)
+        rowst = mod._buf("rowst", (B, 4), torch.float32)
+        part = mod._buf("part", (B * ((ldc + 63) // 64) * 4,), torch.float32)
+        ops.lib.arcface_fwd_fused(st["xh"].data_ptr(), st["whp"].data_ptr(), cos.data_ptr(), ldc, label.data_ptr(), part.data_ptr(),
+                                  part.numel(), rowst.data_ptr(), loss_b.data_ptr(), argmax.data_ptr(), loss.data_ptr(), B, C, D,
+                                  mod.s, mod.m, int(mod.easy_margin), mod._err_flag().data_ptr(), ops._stream())
+        ctx.mod, ctx.st, ctx.cos, ctx.label, ctx.rowst = mod, st, cos, label, rowst       # module scratch, intact until the next forward
         ctx.mark_non_differentiable(argmax)
-        return loss_b.mean(), argmax
+        return loss, argmax
 
     @staticmethod
     def backward(ctx, dloss, _dargmax):
-        ctx.mod._check_gen(ctx.st)
-        # chain rule for a non-unit upstream gradient: out of place (a second backward through a retained graph must not
-        # rescale the saved dcos) with the fp32 scalar (bf16 tensor x fp32 0-dim tensor multiplies in fp32, rounds once)
-        dcos = torch.mul(ctx.dcos, dloss.float(), out=ctx.mod._buf("dcos_scaled", tuple(ctx.dcos.shape), torch.bfloat16))
-        dx = ctx.mod._backward_from_dcos(ctx.st, dcos, ctx.cos)
+        mod, st = ctx.mod, ctx.st
+        mod._check_gen(st)
+        B, C, ldc = st["B"], mod.out_feature, st["ldc"]
+        dloss = dloss.detach().reshape(1).float().contiguous()           # the upstream gradient stays on the device: the kernel reads it
+        dcos = mod._buf("dcos", (B, ldc), torch.bfloat16)
+        if ldc % 256 == 0 and _FUSED_DW:
+            rowvec = mod._buf("rowvec", (2, C), torch.float32)
+            ops.lib.arcface_dcos_rowfix(ctx.cos.data_ptr(), ldc, ctx.label.data_ptr(), ctx.rowst.data_ptr(), dloss.data_ptr(), 1.0 / B,
+                                        st["inv_w"].data_ptr(), dcos.data_ptr(), rowvec.data_ptr(), B, C, mod.s, mod.m,
+                                        int(mod.easy_margin), ops._stream())
+        else:       # small heads (class dimension padded to 8, not 256): dcos from the row statistics, row vectors by their own pass
+            rowvec = None
+            lse = ctx.rowst[:, 0].contiguous()
+            ops.lib.arcface_dcos_from_lse(ctx.cos.data_ptr(), ldc, ctx.label.data_ptr(), lse.data_ptr(),
+                                          (dloss / B).expand(B).contiguous().data_ptr(), dcos.data_ptr(), B, C, 0, mod.s, mod.m,
+                                          int(mod.easy_margin), ops._stream())
+        dx = mod._backward_from_dcos(st, dcos, ctx.cos, rowvec=rowvec)
         return dx, None, None, None
 
 

@@ -57,6 +57,44 @@ def test_arcface_head_matches_reference_golden(golden_dir, i):
     assert torch.equal(am.cpu(), logits.argmax(1).cpu())
 
 
+@pytest.mark.parametrize("B,D,C", [(256, 64, 33000), (256, 64, 5000), (24, 40, 96)])
+def test_fused_loss_paths_agree_with_the_literal_head(B, D, C):
+    """The three routes of forward_loss (mmsim_arcface_fwd_fused): (256, 64, 33 000) -- softmax statistics in the cosine product's
+    epilogue + the one-pass dcos / row-vector backward; (256, 64, 5 000) -- statistics by their own pass (too few tiles for the
+    pipelined GEMM), same backward; (24, 40, 96) -- small head, dcos from the row statistics.  Against the literal API path (logits
+    materialised, torch CrossEntropyLoss: arcface.py:45-63 + multimodal_classifier_train.py:188), a NON-UNIT upstream gradient, and a
+    second backward through the retained graph (the saved state must not have been rescaled by the first)."""
+    from arcface import ArcMarginProduct
+    torch.manual_seed(C)
+    head = ArcMarginProduct(D, C, m=0.5).to(DEV)
+    g = torch.Generator().manual_seed(B + D)
+    x0 = torch.randn(B, D, generator=g)
+    y = torch.randint(0, C, (B,), generator=g)
+    with torch.no_grad():
+        x0[:6] = head.weight.detach().cpu()[y[:6]] * 30 + 0.2 * x0[:6]        # margin branch with cosines near 1
+        y[7] = C - 1                                                             # last class: the ragged tail of the last segment
+    y = y.to(DEV)
+    xl = x0.to(DEV).requires_grad_(True)
+    logits = head(xl, y)
+    ref = torch.nn.CrossEntropyLoss()(logits, y)
+    (0.37 * ref).backward()
+    gx, gw = xl.grad.clone(), head.weight.grad.clone()
+    head.weight.grad.zero_()
+    xf = x0.to(DEV).requires_grad_(True)
+    loss, am = head.forward_loss(xf, y)
+    (0.37 * loss).backward(retain_graph=True)
+    head.check_labels()
+    tag = f"fused_loss_paths[{B}x{D}x{C}]"
+    check(tag, "loss relative difference to the literal path", abs(loss.item() - ref.item()) / abs(ref.item()), 1e-4)
+    assert torch.equal(am, logits.argmax(1))
+    check(tag, "dx max-norm relative difference", relerr(xf.grad, gx), 2e-3)
+    check(tag, "dW max-norm relative difference", relerr(head.weight.grad, gw), 2e-3)
+    g1 = xf.grad.clone()
+    xf.grad = None
+    loss.backward()                                      # second backward, upstream gradient 1
+    check(tag, "second backward: dx(1.0) vs dx(0.37) / 0.37", relerr(xf.grad, g1 / 0.37), 2e-3)
+
+
 def test_arcface_label_out_of_range_raises():
     from arcface import ArcMarginProduct
     head = ArcMarginProduct(32, 10).to(DEV)
