@@ -159,7 +159,13 @@ def test_b4_at_224_random_init_train_mode():
     print(f"\n[B4 @224^2, B={B}, random init, train mode] emb L2 err {e:.4f} (oracle under fp16-storage emulation d0 {d0:.4f}); loss {loss.item():.4f} vs "
           f"{loss_ref.item():.4f} ({le:.2e}); grad L2 median {ge[len(ge) // 2]:.3f} / p90 {ge[int(0.9 * len(ge))]:.3f} over {len(keys)} tensors; oracle {t_oracle:.0f} s")
     tag = "b4_at_224[random-init train mode]"
-    record(tag, "oracle under fp16-storage emulation: embedding relative L2 (d0)", d0, NORTH_STAR)
-    check(tag, "embedding relative L2", e, NORTH_STAR)
+    # MEASURED (r04, MI355X): embedding 1.08 % against the fp32 oracle -- the oracle ITSELF moves by d0 = 1.10 % when nothing but its stored
+    # tensors are rounded to fp16, so the HIP path sits on the storage floor, and that floor is above north_star's 1e-2 for RANDOM-INIT
+    # weights in train mode even at the production geometry (64^2 / B = 16 measured 2.29 %): ~100 batch-statistic BatchNorms over
+    # untrained weights amplify each rounding.  The loss (what training sees) is 1.8e-4 off.  Asserted: a plain absolute bound with a
+    # 15 % margin over the measurement, NOT 1e-2 and not an emulation-relative bound; DESIGN.md section 5 states the number.  The 1e-2
+    # assertions on conditioned (trained-looking) weights at this geometry are in the test above: 0.26-0.27 %.
+    record(tag, "oracle under fp16-storage emulation: embedding relative L2 (d0)", d0, 1.25e-2)
+    check(tag, "embedding relative L2 (random init: above north_star's 1e-2, see comment)", e, 1.25e-2)
     check(tag, "loss relative error", le, NORTH_STAR)
-    check(tag, "median parameter-gradient relative L2", ge[len(ge) // 2], 8e-2)
+    check(tag, "median parameter-gradient relative L2", ge[len(ge) // 2], 5e-2)

@@ -92,7 +92,8 @@ def test_fused_loss_paths_agree_with_the_literal_head(B, D, C):
     g1 = xf.grad.clone()
     xf.grad = None
     loss.backward()                                      # second backward, upstream gradient 1
-    check(tag, "second backward: dx(1.0) vs dx(0.37) / 0.37", relerr(xf.grad, g1 / 0.37), 2e-3)
+    # dcos is rounded to bf16 AFTER the upstream scale: the two backward passes round different values (2^-8 per element at most)
+    check(tag, "second backward: dx(1.0) vs dx(0.37) / 0.37", relerr(xf.grad, g1 / 0.37), 5e-3)
 
 
 def test_arcface_label_out_of_range_raises():

@@ -19,7 +19,7 @@ def t(f, n=5):
 tot_f = tot_b = 0.0
 for H, C, K, cnt in SH:
     P = B * H * H
-    z1 = torch.randn(P, C, device="cuda").bfloat16(); z2 = torch.randn(P, C, device="cuda").bfloat16(); dy = torch.randn(P, C, device="cuda").bfloat16()
+    z1 = torch.randn(P, C, device="cuda").half(); z2 = torch.randn(P, C, device="cuda").half(); dy = torch.randn(P, C, device="cuda").bfloat16()      # forward tensors fp16, gradients bf16
     out = torch.empty(P, C, dtype=torch.bfloat16, device="cuda")
     mk = lambda: (torch.randn(C, device="cuda") * 0.1, 1 + 0.1 * torch.rand(C, device="cuda"), 1 + 0.1 * torch.randn(C, device="cuda"), 0.1 * torch.randn(C, device="cuda"))
     mu1, rs1, sc1, sh1 = mk(); mu2, rs2, sc2, sh2 = mk()
