@@ -345,6 +345,14 @@ int mmsim_dwtile_bwd(const void* dy, const void* z2, const float* scale2, const 
                      const void* resid, const float* w_tap_major, void* out, float* sums1, float* g_tap_major,
                      float* dgamma2, float* dbeta2, int B, int H, int W, int C, int K, float* scratch,
                      unsigned long long scratch_floats, void* stream);
+
+/* The 5 x 5 stride-1 depthwise convolution on the matrix cores (csrc/dwmfma.hip, round 4): same contracts as mmsim_dwtile_fwd / _bwd
+ * for K = 5, S = 1 (timm conv_dw of the k5 MBConv stages under cv_classifier.py:49), whole-plane tiles of 16 channels held PLANAR in
+ * LDS, the taps as banded 4 x 4 operands of v_mfma_f32_4x4x4_16b (block = channel).  Eligible: C % 16 == 0, H, W <= 28.
+ * scratch: >= B * 2 C floats (forward); backward: >= B * (2 + 25) C floats. */
+int mmsim_dw5m_eligible(int B, int H, int W, int C, int K, int S);
+int mmsim_dw5m_fwd(const void* in, const float* xf_scale, const float* xf_shift, const float* w_tap_major, void* z, float* sums,
+                   int B, int H, int W, int C, float* scratch, unsigned long long scratch_floats, void* stream);
 /* Projection 1x1 conv of the early MBConv stages (timm conv_pwl after bn2 + SiLU + SE under cv_classifier.py:49; conv_pw of the
  * depthwise-separable blocks) as one streaming pass:  z3[P,cout] (bf16) = (a2[P,mid] * gate[P / HW, mid]) W3[cout,mid]^T, and the
  * train-mode BatchNorm statistics of the bf16 output ACCUMULATED into sums [2][cout] (pre-zeroed by the caller) -- the same contract

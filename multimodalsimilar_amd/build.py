@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmsim_hip.so")
 STAMP = os.path.join(HERE, ".libmmsim_hip.stamp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["core.hip", "gemm.hip", "gemm_fast.hip", "attention.hip", "rowwise.hip", "head_optim.hip", "conv.hip", "mbconv.hip", "search.hip", "preprocess.hip"]
+SOURCES = ["core.hip", "gemm.hip", "gemm_fast.hip", "attention.hip", "rowwise.hip", "head_optim.hip", "conv.hip", "mbconv.hip", "dwmfma.hip", "search.hip", "preprocess.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-ffp-contract=fast"]
 
 

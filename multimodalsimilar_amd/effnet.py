@@ -79,6 +79,8 @@ _A2_FLY = os.environ.get("MMSIM_A2_FLY", "1") != "0"
 # MMSIM_DWTILE=0: the round-1 depthwise kernels (rows straight from global memory; separate bn_apply / bn_bwd_apply passes)
 # instead of the LDS-tiled ones of csrc/mbconv.hip (A/B switch)
 _DWTILE = os.environ.get("MMSIM_DWTILE", "1") != "0"
+# MMSIM_DW5M=0: the 5 x 5 stride-1 depthwise blocks on the VALU tile kernels (mbconv.hip) instead of the matrix-core kernels (dwmfma.hip)
+_DW5M = os.environ.get("MMSIM_DW5M", "1") != "0"
 # MMSIM_PW_FUSED=0: expand-stage backward as bn_bwd + two GEMMs instead of the one-pass mmsim_pw_expand_bwd (A/B switch)
 _PW_FUSED = os.environ.get("MMSIM_PW_FUSED", "1") != "0"
 # MMSIM_PW_PROJECT=0: projection conv of the early stages through the generic GEMM instead of the streaming kernels (A/B switch)
@@ -361,6 +363,10 @@ class EfficientNet(nn.Module):
         self._bn_arm(st, n + "." + d_bn, sm, P_out)
         if not _DWTILE:
             lib.dwconv_fwd(bs.a1.data_ptr(), bs.wT.data_ptr(), bs.z2.data_ptr(), sm.data_ptr(), B, H, W, b.mid, b.k, b.stride, *self._scr(), s)
+        elif bs.a1 is None and _DW5M and lib.dw5m_eligible(B, H, W, b.mid, b.k, b.stride):
+            # 5 x 5 stride-1 blocks: the depthwise conv on the matrix cores (csrc/dwmfma.hip)
+            lib.dw5m_fwd(bs.z1.data_ptr(), self._bnp(st, n + "." + e_bn, 2).data_ptr(), self._bnp(st, n + "." + e_bn, 3).data_ptr(),
+                         bs.wT.data_ptr(), bs.z2.data_ptr(), sm.data_ptr(), B, H, W, b.mid, *self._scr(), s)
         elif bs.a1 is None:
             lib.dwtile_fwd(bs.z1.data_ptr(), self._bnp(st, n + "." + e_bn, 2).data_ptr(), self._bnp(st, n + "." + e_bn, 3).data_ptr(),
                            bs.wT.data_ptr(), bs.z2.data_ptr(), sm.data_ptr(), B, H, W, b.mid, b.k, b.stride, *self._scr(), s)

@@ -8,7 +8,7 @@ here=$(cd "$(dirname "$0")/.." && pwd)
 obj=/tmp/variant_$$.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -ffp-contract=fast "$@" -c $here/multimodalsimilar_amd/csrc/$src -o $obj
 objs=""
-for f in core gemm gemm_fast attention rowwise head_optim conv mbconv search preprocess; do
+for f in core gemm gemm_fast attention rowwise head_optim conv mbconv dwmfma search preprocess; do
   if [ "$f.hip" = "$src" ]; then objs="$objs $obj"; else objs="$objs $here/multimodalsimilar_amd/build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out $objs
