@@ -353,6 +353,11 @@ int mmsim_dwtile_bwd(const void* dy, const void* z2, const float* scale2, const 
 int mmsim_dw5m_eligible(int B, int H, int W, int C, int K, int S);
 int mmsim_dw5m_fwd(const void* in, const float* xf_scale, const float* xf_shift, const float* w_tap_major, void* z, float* sums,
                    int B, int H, int W, int C, float* scratch, unsigned long long scratch_floats, void* stream);
+int mmsim_dw5m_bwd(const void* dy, const void* z2, const float* scale2, const float* shift2, const float* mean2, const float* rstd2,
+                   const float* sums2, const float* gate, const float* dsq, const void* z1, const float* scale1, const float* shift1,
+                   const float* mean1, const float* rstd1, const float* w_tap_major, void* out, float* sums1, float* g_tap_major,
+                   float* dgamma2, float* dbeta2, int B, int H, int W, int C, float* scratch, unsigned long long scratch_floats,
+                   void* stream);
 /* Projection 1x1 conv of the early MBConv stages (timm conv_pwl after bn2 + SiLU + SE under cv_classifier.py:49; conv_pw of the
  * depthwise-separable blocks) as one streaming pass:  z3[P,cout] (bf16) = (a2[P,mid] * gate[P / HW, mid]) W3[cout,mid]^T, and the
  * train-mode BatchNorm statistics of the bf16 output ACCUMULATED into sums [2][cout] (pre-zeroed by the caller) -- the same contract

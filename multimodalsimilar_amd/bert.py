@@ -29,6 +29,7 @@ from ._lib import MmsimError
 # path, the column-sum pass it saves overlaps with the image tower's stream anyway) and was removed.
 _FUSE_ATTN_BIAS = os.environ.get("MMSIM_FUSE_BIAS_GRADS", "1") != "0"
 # MMSIM_WGRAD_PAIR=0: the attention-output and q|k|v weight gradients of a layer as two launches instead of one grouped launch
+_WGRAD_STREAM = os.environ.get("MMSIM_WGRAD_STREAM", "0") != "0"
 _WGRAD_PAIR = os.environ.get("MMSIM_WGRAD_PAIR", "1") != "0"
 # MMSIM_GELU_PAIR=0: the intermediate activation keeps its pre-activation and the dgrad epilogue recomputes gelu' from it
 # (epilogues 1 / 2) instead of saving gelu' in forward and multiplying in backward (epilogues 6 / 7); A/B switch
@@ -119,6 +120,7 @@ class _Workspace:
             self.dh = [e(M, H), e(M, H)]
             self.dy = [e(M, H), e(M, H)]
             self.dt = e(M, H)
+            self.dt2 = e(M, H)                       # second dropped-gradient buffer: lets the weight-gradient stream read one while the next is written
             self.dhb = e(M, H)
             self.du = e(M, I)
             self.dqkv = e(M, 3 * H)
@@ -344,51 +346,100 @@ class BertModel(nn.Module):
         sk3 = ops.pick_split_k(3 * H, H, M)
         pair = _WGRAD_PAIR and ops.wgrad_pair_eligible(3 * H, H, H, M)
         sk_pair = ops.pick_split_k(4 * H, H, M) if pair else 1
+        # MMSIM_WGRAD_STREAM=1: the weight-gradient products (nothing in the backward pass depends on them) on their own HIP stream.
+        # The data-gradient chain then never waits behind them, and -- the point -- two GEMM launches with different tile durations
+        # share the chip, so that one launch's epilogue write burst meets the other's main loop instead of 256 CUs storing in lockstep.
+        ws_on = _WGRAD_STREAM and dh.is_cuda
+        if ws_on:
+            if getattr(ws, "wstream", None) is None:
+                ws.wstream = torch.cuda.Stream(device=dh.device)
+                ops.register_side_stream(ws.wstream)
+            main = torch.cuda.current_stream()
+            wstream = ws.wstream
+            pending = {}          # buffer name -> event of the weight-gradient launch that still reads it
+
+        def on_wstream(reads, fn):
+            """fn() on the weight-gradient stream, behind everything enqueued on the main stream so far; `reads`: scratch buffers whose
+            next writer (on the main stream) has to wait for it."""
+            if not ws_on:
+                fn()
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            wstream.wait_event(ev)
+            with torch.cuda.stream(wstream):
+                fn()
+                done = torch.cuda.Event()
+                done.record(wstream)
+            for r in reads:
+                pending[r] = done
+
+        def before_write(*names):
+            if ws_on:
+                for r in names:
+                    ev = pending.pop(r, None)
+                    if ev is not None:
+                        main.wait_event(ev)
+
         for li in range(L - 1, -1, -1):
             p = f"encoder.layer.{li}."
             st = ws.st[li]
             # ---- output LayerNorm + FFN
             dy2 = ws.dy[0]
-            dT = ws.dt if m.ph > 0 else dy2
-            ops.ln_bwd(dh, None, ws.y2[li], st[2], st[3], V(p + "output.LayerNorm.weight"), dy2, ws.dt if m.ph > 0 else None,
+            dtA = ws.dt
+            dT = dtA if m.ph > 0 else dy2
+            before_write("dy0", "dtA")
+            ops.ln_bwd(dh, None, ws.y2[li], st[2], st[3], V(p + "output.LayerNorm.weight"), dy2, dtA if m.ph > 0 else None,
                        G(p + "output.LayerNorm.weight"), G(p + "output.LayerNorm.bias"), G(p + "output.dense.bias"),
                        m.ph, m.seed, 4 * li + 2)
-            ops.gemm(dT, ws.u[li], G(p + "output.dense.weight"), trans_a=True, b_kmajor=False, split_k=skI, accumulate=True)
+            on_wstream(("dtA", "dy0"), lambda dT=dT: ops.gemm(dT, ws.u[li], G(p + "output.dense.weight"), trans_a=True, b_kmajor=False,
+                                                              split_k=skI, accumulate=True))
+            before_write("du")
             ops.gemm(dT, SV(p + "output.dense.weight"), ws.du, b_kmajor=False, epilogue=ops.EPI_MUL if _GELU_PAIR else ops.EPI_MUL_GELU_GRAD,
                      aux_in=ws.upre[li])
             # dW and the bias gradient of intermediate.dense from ONE pass over du (the column sums ride on the weight-gradient MFMAs)
-            ops.gemm_wgrad_colsum(ws.du, ws.h1[li], G(p + "intermediate.dense.weight"), G(p + "intermediate.dense.bias"), skI)
+            on_wstream(("du",), lambda: ops.gemm_wgrad_colsum(ws.du, ws.h1[li], G(p + "intermediate.dense.weight"),
+                                                             G(p + "intermediate.dense.bias"), skI))
             ops.gemm(ws.du, SV(p + "intermediate.dense.weight"), ws.dhb, b_kmajor=False)
             # ---- attention-output LayerNorm: dh1 = dy2 (residual) + dhb
             dy1 = ws.dy[1]
-            dT = ws.dt if m.ph > 0 else dy1
+            dtB = ws.dt2 if ws_on else ws.dt
+            dT = dtB if m.ph > 0 else dy1
+            before_write("dy1", "dtB")
             ops.ln_bwd(dy2, ws.dhb, ws.y1[li], st[0], st[1], V(p + "attention.output.LayerNorm.weight"), dy1,
-                       ws.dt if m.ph > 0 else None, G(p + "attention.output.LayerNorm.weight"),
+                       dtB if m.ph > 0 else None, G(p + "attention.output.LayerNorm.weight"),
                        G(p + "attention.output.LayerNorm.bias"), G(p + "attention.output.dense.bias"), m.ph, m.seed,
                        4 * li + 1)
             dT_o = dT
             if not pair:
-                ops.gemm(dT, ws.ctx[li], G(p + "attention.output.dense.weight"), trans_a=True, b_kmajor=False, split_k=skH,
-                         accumulate=True)
+                on_wstream(("dtB", "dy1"), lambda dT=dT: ops.gemm(dT, ws.ctx[li], G(p + "attention.output.dense.weight"), trans_a=True,
+                                                                  b_kmajor=False, split_k=skH, accumulate=True))
             ops.gemm(dT, SV(p + "attention.output.dense.weight"), ws.dctx, b_kmajor=False)
             # ---- attention
             qkv_db = fl._view(fl.grad, p + "attention.self.query.bias", (3 * H,))
+            before_write("dqkv")
             ops.attn_bwd(ws.qkv[li], m.mask, ws.ctx[li], ws.dctx, ws.lse[li], ws.dqkv, B, S, nh, H, m.pa, m.seed, 4 * li + 3,
                          dbias=qkv_db if _FUSE_ATTN_BIAS else None)                               # + the q|k|v bias gradients
             if not _FUSE_ATTN_BIAS:
                 ops.colsum(ws.dqkv, qkv_db)
             if pair:      # q|k|v (48 tiles) and attention-output (16 tiles) weight gradients as one 256-block launch
-                ops.gemm_wgrad_pair(ws.dqkv, ws.h[li], fl._view(fl.grad, p + "attention.self.query.weight", (3 * H, H)),
-                                    dT_o, ws.ctx[li], G(p + "attention.output.dense.weight"), sk_pair)
+                on_wstream(("dqkv", "dtB", "dy1"), lambda: ops.gemm_wgrad_pair(
+                    ws.dqkv, ws.h[li], fl._view(fl.grad, p + "attention.self.query.weight", (3 * H, H)),
+                    dT_o, ws.ctx[li], G(p + "attention.output.dense.weight"), sk_pair))
             else:
-                ops.gemm(ws.dqkv, ws.h[li], fl._view(fl.grad, p + "attention.self.query.weight", (3 * H, H)), trans_a=True,
-                         b_kmajor=False, split_k=sk3, accumulate=True)
+                on_wstream(("dqkv",), lambda: ops.gemm(ws.dqkv, ws.h[li], fl._view(fl.grad, p + "attention.self.query.weight", (3 * H, H)),
+                                                      trans_a=True, b_kmajor=False, split_k=sk3, accumulate=True))
             nxt = ws.dh[1] if dh is ws.dh[0] else ws.dh[0]
             ops.gemm(ws.dqkv, fl.sview(p + "attention.self.query.weight", (3 * H, H)), nxt, b_kmajor=False,
                      epilogue=ops.EPI_ADD, aux_in=dy1)
             dh = nxt
             if self.grad_ready_hook:
+                if ws_on:
+                    main.wait_stream(wstream)          # the layer's weight gradients are final before their range is handed to the exchange
+                    pending.clear()
                 self.grad_ready_hook(fl, *fl.span(p + "attention.self.query.weight", p + "output.LayerNorm.bias"))
+        if ws_on:
+            main.wait_stream(wstream)                  # every weight gradient is in the flat buffer before the optimiser / exchange reads it
         ops.embed_ln_bwd(dh, m.ids, m.tts, V("embeddings.word_embeddings.weight"), V("embeddings.position_embeddings.weight"),
                          V("embeddings.token_type_embeddings.weight"), V("embeddings.LayerNorm.weight"),
                          G("embeddings.word_embeddings.weight"), G("embeddings.position_embeddings.weight"),

@@ -1594,18 +1594,19 @@ extern "C" int mmsim_dwconv_fwd(const void* a, const float* w_tap_major, void* z
   // and is best served by the row-at-a-time form.  MMSIM_DW_VARIANT=0/1 forces one form (tools/bench_dw.py).
   static int variant = -2;
   if (variant == -2) { const char* e = getenv("MMSIM_DW_VARIANT"); variant = e ? atoi(e) % 10 : -1; }
-  const int Vv = variant >= 0 ? variant : (K == 3 ? 1 : 0);
+  // K = 5 never takes the up-front form: its instantiations need 160 registers of loads in flight and compiled to 256 VGPRs + 1.5 KB of
+  // scratch per lane -- they are no longer instantiated; MMSIM_DW_VARIANT only selects among the 3 x 3 forms.
+  const int Vv = K == 5 ? 0 : (variant >= 0 ? variant : 1);
   g.d_strip = make_fastdiv((g.Wo + 3) / 4); g.d_rows = make_fastdiv(g.Ho);
   const int nitems = B * g.Ho * ((g.Wo + 3) / 4);
   const int ipb = rows_per_block_for(nitems, nr_of(C));
   dim3 grid((nitems + ipb - 1) / ipb, cg_grid_y(C));
   REQ_SCRATCH((size_t)grid.x * 2 * C, "dwconv_fwd");
 #define DWF(KK, SS, TT, VV) hipLaunchKernelGGL((dwconv_fwd_kernel<KK, SS, TT, VV>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)a, w_tap_major, (f16*)z, scratch, g, ipb)
-#define DWF_KS(TT, VV)                                        \
-  if (K == 3 && S == 1) DWF(3, 1, TT, VV); else if (K == 3 && S == 2) DWF(3, 2, TT, VV); \
-  else if (K == 5 && S == 1) DWF(5, 1, TT, VV); else DWF(5, 2, TT, VV);
-  if (Vv == 1) { DWF_KS(4, 1) } else { DWF_KS(4, 0) }
-#undef DWF_KS
+  if (K == 3 && S == 1) { if (Vv == 1) DWF(3, 1, 4, 1); else DWF(3, 1, 4, 0); }
+  else if (K == 3 && S == 2) { if (Vv == 1) DWF(3, 2, 4, 1); else DWF(3, 2, 4, 0); }
+  else if (K == 5 && S == 1) DWF(5, 1, 4, 0);
+  else DWF(5, 2, 4, 0);
 #undef DWF
   launch_reduce(scratch, grid.x, 2 * C, sums, 1, (hipStream_t)stream);
   return mmsim_check_launch("dwconv_fwd");

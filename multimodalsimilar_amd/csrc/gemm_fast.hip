@@ -638,6 +638,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
   // epilogue halves, so that the chip-wide prologue burst (MI355X_MICROARCH.md: ~9k cycles per 96 KiB with every CU in its
   // prologue) finds its lines on-die: 1661 / 1681 us against 1675 / 1675 us over the eight forward / data-gradient products of a
   // layer (tools/bench_gemm_epi.py, alternating builds on one box) -- no gain; the burst is not an L2-miss problem.
+  // THE ABORT OF THAT EXPERIMENT (gpurun_out/ab_pf2.log of round 3, HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION "beyond the largest legal
+  // address", both A/B rounds of the first build): the successor was computed as wg + 32 with NO range check.  For the
+  // last 32 workgroups of the launch (the tail of the last XCD's chunk) wg + 32 >= tiles x splits, so the decoded (split, tile) was past
+  // the end -- tile row >= tiles_m (rows >= M of A) and, with split-K, split >= splits (k >= K) -- and the loads were REAL
+  // register-destination loads, not hints: base + (row past M) * lda lies outside the operand and, for the tensor that sits last in
+  // the allocator's range, outside the process's aperture.  Every other workgroup prefetched a valid successor, which is why small
+  // test shapes (whose last workgroups' successors still landed inside a neighbouring allocation) passed.  The second build
+  // (ab_pf1.log, eight minutes later) predicated the prefetch on wg + 32 < nwg and ran clean.  RULE for any next-tile prefetch brought
+  // back here: (a) wave-uniform predicate `successor < tiles x splits`, (b) clamp the row / k indices to the operand anyway (clamped
+  // address, discarded value: the idiom of the generic kernels), (c) run tools/bench_gemm.py once at M = 32 768 -- the fault needs the
+  // tail workgroups of a LARGE launch.
   const bool fs = split == 0;
   float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
   if (PP64_DBG(p) & 8) {

@@ -81,6 +81,10 @@ _A2_FLY = os.environ.get("MMSIM_A2_FLY", "1") != "0"
 _DWTILE = os.environ.get("MMSIM_DWTILE", "1") != "0"
 # MMSIM_DW5M=0: the 5 x 5 stride-1 depthwise blocks on the VALU tile kernels (mbconv.hip) instead of the matrix-core kernels (dwmfma.hip)
 _DW5M = os.environ.get("MMSIM_DW5M", "1") != "0"
+# MMSIM_DW5M_BWD: the fused backward on the matrix cores too -- 1 (default): where it measured faster than the VALU tile kernel (planes of
+# at least 14 x 14: 379 vs 401 us at 28^2 x 336, 270 vs 335 us at 14^2 x 960; at 7^2 x 1632 it is 172 vs 151 us and stays off), 2: every
+# eligible shape, 0: never
+_DW5M_BWD = int(os.environ.get("MMSIM_DW5M_BWD", "1"))
 # MMSIM_PW_FUSED=0: expand-stage backward as bn_bwd + two GEMMs instead of the one-pass mmsim_pw_expand_bwd (A/B switch)
 _PW_FUSED = os.environ.get("MMSIM_PW_FUSED", "1") != "0"
 # MMSIM_PW_PROJECT=0: projection conv of the early stages through the generic GEMM instead of the streaming kernels (A/B switch)
@@ -592,9 +596,14 @@ class EfficientNet(nn.Module):
             if b.type == "ir":
                 en = n + "." + e_bn
                 dpre1 = E(P_in, b.mid)
-                lib.dwtile_bwd(*common, bs.z1.data_ptr(), bnp(en, 2), bnp(en, 3), bnp(en, 0), bnp(en, 1), None, bs.wT.data_ptr(),
-                               dpre1.data_ptr(), self._sums(st, en, "b").data_ptr(), gT.data_ptr(), G(dn + ".weight").data_ptr(),
-                               G(dn + ".bias").data_ptr(), B, Hn, Wn, b.mid, b.k, *self._scr(), s)
+                if _DW5M_BWD and (_DW5M_BWD == 2 or Hn * Wn >= 196) and lib.dw5m_eligible(B, Hn, Wn, b.mid, b.k, 1):       # 5 x 5 blocks: on the matrix cores (csrc/dwmfma.hip)
+                    lib.dw5m_bwd(*common, bs.z1.data_ptr(), bnp(en, 2), bnp(en, 3), bnp(en, 0), bnp(en, 1), bs.wT.data_ptr(),
+                                 dpre1.data_ptr(), self._sums(st, en, "b").data_ptr(), gT.data_ptr(), G(dn + ".weight").data_ptr(),
+                                 G(dn + ".bias").data_ptr(), B, Hn, Wn, b.mid, *self._scr(), s)
+                else:
+                    lib.dwtile_bwd(*common, bs.z1.data_ptr(), bnp(en, 2), bnp(en, 3), bnp(en, 0), bnp(en, 1), None, bs.wT.data_ptr(),
+                                   dpre1.data_ptr(), self._sums(st, en, "b").data_ptr(), gT.data_ptr(), G(dn + ".weight").data_ptr(),
+                                   G(dn + ".bias").data_ptr(), B, Hn, Wn, b.mid, b.k, *self._scr(), s)
             else:
                 dx_in = E(P_in, b.cin)
                 lib.dwtile_bwd(*common, bs.x_in.data_ptr(), None, None, None, None, dx.data_ptr() if b.skip else None,

@@ -23,7 +23,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 NAME = "efficientnet_b4"
 # entry points whose use at 224^2 is asserted (forward, then backward)
-STREAMING = ("pw_expand_fwd", "pw_project_fwd_xf", "pw_project_fwd", "dwtile_fwd", "pw_project_bwd_xf", "pw_expand_bwd", "dwtile_bwd")
+STREAMING = ("pw_expand_fwd", "pw_project_fwd_xf", "pw_project_fwd", "dwtile_fwd", "dw5m_fwd", "pw_project_bwd_xf", "pw_expand_bwd", "dwtile_bwd",
+             "dw5m_bwd")
 
 
 class _Counter:
@@ -77,7 +78,9 @@ def test_b4_at_224_conditioned_eval_and_train_match_the_oracle():
     with _Counter(STREAMING) as cnt, torch.no_grad():
         emb = model.predict_emb(xe.to(DEV))
     e_eval = l2err(emb, ref)
-    assert cnt.n["pw_expand_fwd"] >= 3 and cnt.n["pw_project_fwd_xf"] + cnt.n["pw_project_fwd"] >= 6 and cnt.n["dwtile_fwd"] >= 28, cnt.n
+    # 32 depthwise layers: the tiled VALU kernels (3 x 3 and the stride-2 blocks) + the matrix-core kernels (the 16 5 x 5 stride-1 blocks)
+    assert cnt.n["pw_expand_fwd"] >= 3 and cnt.n["pw_project_fwd_xf"] + cnt.n["pw_project_fwd"] >= 6, cnt.n
+    assert cnt.n["dwtile_fwd"] + cnt.n["dw5m_fwd"] >= 28 and cnt.n["dw5m_fwd"] == 16, cnt.n
     # ---- train mode (batch statistics), forward + backward
     sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
     emb_ref = effnet_ref.cv_predict_emb(sdr, NAME, x, use_fc=False, training=True)
@@ -97,7 +100,9 @@ def test_b4_at_224_conditioned_eval_and_train_match_the_oracle():
         ops.set_deterministic(False)
     # the 112^2 / 56^2 stages ran the streaming kernels and the tiled depthwise kernels, forward and backward (two forwards here)
     assert cnt.n["pw_expand_fwd"] >= 6 and cnt.n["pw_project_fwd_xf"] + cnt.n["pw_project_fwd"] >= 12, cnt.n
-    assert cnt.n["pw_project_bwd_xf"] >= 5 and cnt.n["pw_expand_bwd"] >= 8 and cnt.n["dwtile_bwd"] >= 28 and cnt.n["dwtile_fwd"] >= 56, cnt.n
+    assert cnt.n["pw_project_bwd_xf"] >= 5 and cnt.n["pw_expand_bwd"] >= 8, cnt.n
+    assert cnt.n["dwtile_bwd"] + cnt.n["dw5m_bwd"] >= 28 and cnt.n["dwtile_fwd"] + cnt.n["dw5m_fwd"] >= 56 and cnt.n["dw5m_fwd"] == 32, cnt.n
+    assert cnt.n["dw5m_bwd"] == 9, cnt.n               # the 28^2 and 14^2 5 x 5 blocks (3 + 6); the 7^2 ones stay on the VALU kernel (measured faster there)
     named = dict(model.named_parameters())
     gmax = max(v.norm().item() for v in grads.values())
     keys = [k for k in named if k in grads and named[k].grad is not None and grads[k].norm().item() > 1e-4 * gmax]
