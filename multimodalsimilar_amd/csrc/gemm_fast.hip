@@ -649,6 +649,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
   // back here: (a) wave-uniform predicate `successor < tiles x splits`, (b) clamp the row / k indices to the operand anyway (clamped
   // address, discarded value: the idiom of the generic kernels), (c) run tools/bench_gemm.py once at M = 32 768 -- the fault needs the
   // tail workgroups of a LARGE launch.
+  // Round 4, measured and not kept: the STAGGERED PERSISTENT form without idle time -- one workgroup per CU walking the virtual block ids
+  // b, b + G, ..., the workgroups dealt into 2 or 4 phase groups, group g > 0 splitting ITS OWN first tile in K (upper K range first, the
+  // fp32 accumulators parked in a private 256-KiB slab as a raw register dump, the lower K range at the very end on top of the parked sums:
+  // no cross-workgroup communication), so that tile boundaries -- and the epilogue write bursts, which are what the K = 1 024 products
+  // lose 30-47 % of their time to (qkv 207 us against 147 us of main loop, the GELU-pair product 370 against 196; 256 CUs store in
+  // lockstep and each gets 1 / 256 of the HBM write bandwidth) -- stay g / groups of a tile apart for the whole launch.  Results correct;
+  // tools/bench_gemm_epi.py, alternating on one box: eight forward / data-gradient products 2 115-2 180 us (2 groups / 4 groups) against
+  // 1 710-1 733 us.  Not a verdict on the idea: wrapping the kernel body in the tile loop took hipcc's allocation from 210-221 to 247
+  // registers (every instantiation, the single-trip ones included) and the persistent instantiations to 256 + 224-336 B of scratch per
+  // lane IN the main loop.  What a next attempt needs: the tile loop around a body whose per-lane invariants are recomputed per tile
+  // (LICM hoists the epilogue's and the fragment reads' lane offsets across the main loop), or the loop written in assembly.
   const bool fs = split == 0;
   float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
   if (PP64_DBG(p) & 8) {
