@@ -655,11 +655,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
   // no cross-workgroup communication), so that tile boundaries -- and the epilogue write bursts, which are what the K = 1 024 products
   // lose 30-47 % of their time to (qkv 207 us against 147 us of main loop, the GELU-pair product 370 against 196; 256 CUs store in
   // lockstep and each gets 1 / 256 of the HBM write bandwidth) -- stay g / groups of a tile apart for the whole launch.  Results correct;
-  // tools/bench_gemm_epi.py, alternating on one box: eight forward / data-gradient products 2 115-2 180 us (2 groups / 4 groups) against
-  // 1 710-1 733 us.  Not a verdict on the idea: wrapping the kernel body in the tile loop took hipcc's allocation from 210-221 to 247
-  // registers (every instantiation, the single-trip ones included) and the persistent instantiations to 256 + 224-336 B of scratch per
-  // lane IN the main loop.  What a next attempt needs: the tile loop around a body whose per-lane invariants are recomputed per tile
-  // (LICM hoists the epilogue's and the fragment reads' lane offsets across the main loop), or the loop written in assembly.
+  // First build: wrapping the kernel body in the tile loop made hipcc hoist every per-lane invariant (fragment read offsets, epilogue
+  // addresses) out of the loop and across the main loop: 256 registers + 224-336 B of scratch per lane, 2 115-2 180 us over the eight
+  // forward / data-gradient products of a layer (tools/bench_gemm_epi.py) against 1 710-1 733.  Second build: the thread index
+  // "laundered" once per tile (`asm volatile("" : "+v"(tid))`, everything per-lane derives from it) -- 220-222 registers, no scratch.
+  // Measured, alternating with the plain launch on one box, two rounds: 2 groups 1 718 / 1 731 us, 4 groups 1 730 / 1 739, 8 groups
+  // 1 791 / 1 780 against 1 641 / 1 647 (and 1 640 / 1 630 for the kernel before the change): 5-9 % SLOWER, every shape, more groups
+  // worse.  So the result of round 3's sleep stagger stands and is now free of its idle time: the lockstep of the rounds is NOT what
+  // the epilogues cost.  What they cost is their own work: the GELU pair is ~25 vector instructions on each of 134 M elements (~56 us
+  // of the chip's whole VALU rate per launch, with the matrix pipes idle) plus 2 x 268 MB of stores; de-phasing adds two pipeline
+  // ramps and a 256-KiB park / restore per staggered workgroup and takes the L2 panel sharing of lockstep neighbours away.
   const bool fs = split == 0;
   float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
   if (PP64_DBG(p) & 8) {
