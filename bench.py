@@ -15,7 +15,7 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                  run on two HIP streams, so inside the timed region these launches time-share the chip with image-tower
                  kernels; `achieved_exclusive` is the same measurement over two untimed steps with one stream, taken right
                  after the timed region; `traffic` is the fabric-side bytes per launch from separate rocprofv3 --pmc passes
-                 (profiles/r03_pmc_gemm_pp64.json);
+                 (profiles/r04_pmc_gemm_pp64.json);
   cpu_baseline - the oracle's CPU restatement of the same step (oracle/step_ref.py, kind "port") on the host cores,
                  on a bounded sample (same model, B_cpu pairs per step).
 """
@@ -64,7 +64,7 @@ def _pmc_traffic(config):
     """HBM-side bytes per launch of the dominant kernel (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured in separate
     rocprofv3 --pmc passes over the same four forward shapes (tools/pmc_gemm.py) and committed under profiles/; counters
     cannot be read inside this process, so the figure is only reported for the workload it was measured on (cfg4 / cfg3)."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_gemm_pp64.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_gemm_pp64.json")
     if config not in ("cfg4", "cfg3") or not os.path.exists(path):
         return None, None
     with open(path) as f:
@@ -319,7 +319,7 @@ def main():
             "roofline": None if g is None else {
                 "bound": "mfma", "kernel": "gemm_pp64_kernel<false,true,256> (Y = X W^T: 256x256 tiles, 64-deep LDS-DMA slices, ping-pong wave groups, bf16 MFMA 16x16x32, fp32 accumulate)",
                 "achieved": g["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": _pmc_traffic(args.config)[0], "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_pmc_gemm_pp64.json, re-measured with this round's kernel)",
+                "traffic": _pmc_traffic(args.config)[0], "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r04_pmc_gemm_pp64.json, re-measured with this round's kernel)",
                 "algorithmic_bytes_per_launch": _pmc_traffic(args.config)[1],
                 "launches": g["launches"], "avg_launch_us": g["avg_us"], "measured_over": roof_from,
                 "concurrent_with": "image-tower kernels on a second stream" if g_excl else None,
