@@ -702,6 +702,28 @@ __global__ __launch_bounds__(512, 2) void gemm_pp64_kernel(GemmParams p) {
   if constexpr (MT == 8) epi_half(*reinterpret_cast<f4 (*)[4][4]>(&acc[4][0]), 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 4, measured and not kept: ONE WAVE PER SIMD, 128 x 128 PER WAVE (gemm_w4_kernel; VERDICT r3 item 2 "measure it instead of costing
+// it").  256 x 256 tile, four waves as 2 x 2, 8 x 8 MFMA tiles = 256 accumulators in the AGPR half of the unified file, a double-buffered
+// fragment set (2 x 16 x 4 registers; 16 ds_read_b128 per 64 MFMAs instead of pp64's 12 per 32), the rings of gemm_pp64_kernel, ONE barrier
+// per 64-deep slice (between its two steps), the next step's fragments read behind MFMA rows 0..3 and the LDS-DMA pieces of B_{u+2} then
+// A_{u+3} behind the odd step's rows (B before A: vmcnt counts in issue order -- interleaving them let vmcnt(8) pass with half of B in
+// flight, a cold-cache-only wrong result that the after-load re-check of tools/bench_gemm.py caught).  What it took to get a clean loop
+// out of hipcc (148-208 VGPRs + 256 AGPRs, no scratch, the steady-state slice = 128 MFMAs + 32 reads + 16 DMAs + ~40 scalar):
+//   (a) every fragment read as per-lane base + IMMEDIATE offset (`ds_read_b128 %0, %1 offset:%2`), every DMA piece as wave-uniform base +
+//       one of two per-lane offsets; (b) the epilogue's four 64 x 64 quadrants written out (a runtime quadrant index sends all 256
+//       accumulators through scratch); (c) the tail peeled so the steady loop is ONE basic block; (d) the MFMAs as in-place inline asm
+//       ("+a" tied accumulator): with the builtin and no free AGPR the allocator rotates ~180 accumulator registers per slice at the loop
+//       header (v_accvgpr_mov chains, ~1/3 of the loop's issue slots).
+// Forward layout (NT, bias epilogue), M = 32 768, tools/bench_gemm.py, alternating processes on one box, TFLOP/s, w4 | pp64 | hipBLASLt:
+//   qkv (N 3072, K 1024) 1 027 | 1 058 | 1 075      o (N 1024, K 1024) 1 030 | 1 082 | 1 144
+//   ffn1 (N 4096, K 1024) 1 080 | 1 145 | 1 250     ffn2 (N 1024, K 4096) 1 339 | 1 315 | 1 434
+// Solving tile time = (K / 64) s + o from the K = 1 024 and K = 4 096 rows: s = 1.44 us per slice and o = 10.3 us per tile for w4,
+// s = 1.37 / o = 8.0 for hipBLASLt (pp64 sits between): a slice is 2 048 MFMA cycles, i.e. all three run the matrix pipes at an
+// EFFECTIVE ~1.45 GHz in the main loop and differ by <= 5 % there; the fixed ~8-10 us per tile (prologue ramp + the 128-KiB epilogue
+// with the matrix pipes idle) is 25-30 % of a K = 1 024 tile and is where the forms differ.  w4 halves the fragment bytes per MFMA
+// and gains 2 % at K = 4 096, but its epilogue runs on four waves instead of eight and loses 3-6 % at K = 1 024.  Not kept; the
+// >= 10 % main-loop gain that would have justified the NN / TN forms is not there to be had -- the main loop is not LDS-bound.
 // The row-fix weight gradient (EPI_ROWFIX: C[M,N] f32 = r[m] (A^T B - aux r'[m]), the ArcFace head's dW with the backward of
 // F.normalize folded in) on the pipelined 256 x 256 kernel although M (the class count) is not a multiple of 256: A is stored
 // [K][lda] with lda covering M rounded up to 256 (head.py pads the class dimension of dcos with zero columns), so the operand
