@@ -180,6 +180,44 @@ __device__ __forceinline__ bf8 read_frag(const char* lds, int rbase, int ks, int
   }
 }
 
+// The epilogue of the generic kernels (gemm_body, gemm_ring_body): a wave's 64 x 64 sub-tile leaves through its LDS staging region
+// (whole cache-line row segments); `smem` is free when this is called (the caller's last barrier is behind every operand read).
+template <int FMT>
+__device__ __forceinline__ void gemm_tail(const GemmParams& p, f4 (&acc)[4][4], const bool fs, const int tm, const int m0, const int n0,
+                                          const int wm, const int wn, const int wave, const int lane, char* smem) {
+  const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;
+  float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
+  if (p.stats) {                     // launch-uniform: bf16 output + BatchNorm column statistics of this M-tile
+    float cs[4], cq[4];
+    stats_epilogue<FMT == 1>(p, acc, row0, col0, lane, stg, cs, cq);
+    __syncthreads();                 // all staging reads done: the region is reused for the cross-wave sum
+    float* red = reinterpret_cast<float*>(smem);          // [wave][2][64]
+    if (lane < 16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { red[(wave * 2 + 0) * 64 + lane * 4 + e] = cs[e]; red[(wave * 2 + 1) * 64 + lane * 4 + e] = cq[e]; }
+    }
+    __syncthreads();
+    if (wm == 0) {                   // waves 0, 1 (wn = 0, 1) add their partner wave (wm = 1) and write 64 columns each
+      const int n = col0 + lane;
+      if (n < p.N) {
+        float* slab = p.stats + (size_t)tm * 2 * p.N;
+        slab[n] = red[(wave * 2 + 0) * 64 + lane] + red[((wave + 2) * 2 + 0) * 64 + lane];
+        slab[p.N + n] = red[(wave * 2 + 1) * 64 + lane] + red[((wave + 2) * 2 + 1) * 64 + lane];
+      }
+    }
+    return;
+  }
+  if (FMT == 1 && !p.c_f32) { f16_epilogue(p, acc, row0, col0, lane, stg); return; }
+  if (!p.c_f32) fast_epilogue_epi<0, true>(p, acc, row0, col0, lane, fs, stg);
+  else if (p.atomic) fast_epilogue<EPI_NONE, 3, true>(p, acc, row0, col0, lane, fs, stg);
+  else if (p.accum && p.epi == EPI_ROWFIX) fast_epilogue<EPI_ROWFIX, 2, true>(p, acc, row0, col0, lane, fs, stg);
+  else if (p.accum) fast_epilogue<EPI_NONE, 2, true>(p, acc, row0, col0, lane, fs, stg);
+  else if (p.epi == EPI_TANH) fast_epilogue<EPI_TANH, 1, true>(p, acc, row0, col0, lane, fs, stg);
+  else if (p.epi == EPI_NONE) fast_epilogue<EPI_NONE, 1, true>(p, acc, row0, col0, lane, fs, stg);
+  else if (p.epi == EPI_ROWFIX) fast_epilogue<EPI_ROWFIX, 1, true>(p, acc, row0, col0, lane, fs, stg);
+  else gemm_epilogue(p, acc, row0, col0, lane, fs);          // f32 output with a fused epilogue: direct form
+}
+
 template <bool TA, bool TB_KMAJOR, int XF, int FMT = 0>   // XF: 0 none, 1 transform A, 2 transform B; FMT: GemmParams::fmt
 __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, char* smem) {
   static_assert(FMT != 2 || (XF != 1), "fmt 2 converts the B operand");
@@ -259,40 +297,229 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bid, ch
   }
 
   // staged epilogue (whole cache-line row segments; the operand stages are free after the last barrier)
-  {
-    const bool fs = split == 0;
-    const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;
-    float* stg = reinterpret_cast<float*>(smem) + wave * (64 * EP_PITCH);
-    if (p.stats) {                     // launch-uniform: bf16 output + BatchNorm column statistics of this M-tile
-      float cs[4], cq[4];
-      stats_epilogue<FMT == 1>(p, acc, row0, col0, lane, stg, cs, cq);
-      __syncthreads();                 // all staging reads done: the region is reused for the cross-wave sum
-      float* red = reinterpret_cast<float*>(smem);          // [wave][2][64]
-      if (lane < 16) {
+  gemm_tail<FMT>(p, acc, split == 0, tm, m0, n0, wm, wn, wave, lane, smem);
+}
+
+// =========================================================================================================================
+// RING form of the 128 x 128 generic product (round 4): the same tile, wave layout and epilogues as gemm_body, but the
+// operands arrive by LDS-DMA through a ring of 32-deep stages (16 KiB: A 128 rows x 64 B | B 128 x 64 B or 32 k-rows x 256 B) with
+// TWO OR THREE STAGES IN FLIGHT per workgroup.  gemm_body keeps ONE register-staged K-step in flight: at the image tower's late-stage
+// shapes (14 x 14 / 7 x 7 planes: M = 50 176 / 12 544 pixels, 112-448 / 672-2 688 channels) a K-step costs a memory round trip
+// (~2 us against ~0.3 us of MFMAs) and the products ran at 0.8-2.9 TB/s of operand + result bytes.  Two workgroups per CU (<= 80 KiB).
+//   iteration t:  vmcnt -> my pieces of stage t landed | barrier (everybody's landed; everybody is done reading stage t - 1)
+//                 | issue stage t + NS - 1 into the slot of stage t - 1 | fragments of stage t | 16 MFMAs per wave
+// Ragged edges: rows past M / N re-read the last row (their outputs are predicated off in the epilogues), 16-byte chunks past the K
+// range and columns past N of a transposed operand read a zero chunk instead (g_rg_zero) -- the DMA cannot mask.
+// GATE (forward projection conv): A = a2 * gate[pixel / HW][channel]; the gate rows of the <= 4 images a tile touches are staged once
+// per tile as fp16 [4][Kp] and multiplied into the A fragments (v_pk_mul_f16) -- the product of two fp16 values rounded to fp16, where
+// gemm_body's xform_tile multiplies by the fp32 gate: one more rounding of the gate (2^-11 relative).
+typedef void __attribute__((address_space(3))) * rg_lds_ptr;
+typedef const void __attribute__((address_space(1))) * rg_glb_ptr;
+#define RG_STG 16384
+__device__ __attribute__((aligned(64))) const unsigned int g_rg_zero[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+__device__ __forceinline__ bf8 rg_read_b128(uint32_t a, int imm_unused = 0) {
+  bf8 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ bf8 rg_read_b128_off(uint32_t a) {
+  bf8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ bf8 rg_read_tr_off(uint32_t a) {     // k rows 8g + q (lo) and + 4 (hi) of a 256-byte-row image
+  s4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(OFF + 4 * 256));
+  return __builtin_bit_cast(bf8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// per-lane source state of one operand: two 1-KiB pieces per wave and stage
+struct RgSrc { const char* base[2]; int kofs; int kstep; bool colok[2]; };
+
+template <bool TRANS>      // TRANS = false: X[row][k] (k contiguous); true: X[k][col]
+__device__ __forceinline__ void rg_src_init(RgSrc& o, const bf16* X, int ld, int r0, int R, int kbeg, int wave, int lane) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { red[(wave * 2 + 0) * 64 + lane * 4 + e] = cs[e]; red[(wave * 2 + 1) * 64 + lane * 4 + e] = cq[e]; }
-      }
-      __syncthreads();
-      if (wm == 0) {                   // waves 0, 1 (wn = 0, 1) add their partner wave (wm = 1) and write 64 columns each
-        const int n = col0 + lane;
-        if (n < p.N) {
-          float* slab = p.stats + (size_t)tm * 2 * p.N;
-          slab[n] = red[(wave * 2 + 0) * 64 + lane] + red[((wave + 2) * 2 + 0) * 64 + lane];
-          slab[p.N + n] = red[(wave * 2 + 1) * 64 + lane] + red[((wave + 2) * 2 + 1) * 64 + lane];
-        }
-      }
-      return;
+  for (int i = 0; i < 2; ++i) {
+    const int blk = wave * 2 + i;
+    if (!TRANS) {
+      const int row = blk * 16 + (lane >> 2), c = (lane & 3) ^ ((lane >> 4) & 3);
+      o.base[i] = reinterpret_cast<const char*>(X + (size_t)min(r0 + row, R - 1) * ld + kbeg + c * 8);
+      o.kofs = c * 8; o.colok[i] = true;
+    } else {
+      const int k = blk * 4 + (lane >> 4), pc = lane & 15;
+      const int rc = (((pc >> 1) ^ tr_key(k)) << 1) | (pc & 1);
+      const int col = r0 + rc * 8;
+      o.colok[i] = col < R;
+      o.base[i] = reinterpret_cast<const char*>(X + (size_t)(kbeg + k) * ld + (col < R ? col : r0));
+      o.kofs = k;          // differs per piece: recomputed in rg_issue (blk * 4 + (lane >> 4))
     }
-    if (FMT == 1 && !p.c_f32) { f16_epilogue(p, acc, row0, col0, lane, stg); return; }
-    if (!p.c_f32) fast_epilogue_epi<0, true>(p, acc, row0, col0, lane, fs, stg);
-    else if (p.atomic) fast_epilogue<EPI_NONE, 3, true>(p, acc, row0, col0, lane, fs, stg);
-    else if (p.accum && p.epi == EPI_ROWFIX) fast_epilogue<EPI_ROWFIX, 2, true>(p, acc, row0, col0, lane, fs, stg);
-    else if (p.accum) fast_epilogue<EPI_NONE, 2, true>(p, acc, row0, col0, lane, fs, stg);
-    else if (p.epi == EPI_TANH) fast_epilogue<EPI_TANH, 1, true>(p, acc, row0, col0, lane, fs, stg);
-    else if (p.epi == EPI_NONE) fast_epilogue<EPI_NONE, 1, true>(p, acc, row0, col0, lane, fs, stg);
-    else if (p.epi == EPI_ROWFIX) fast_epilogue<EPI_ROWFIX, 1, true>(p, acc, row0, col0, lane, fs, stg);
-    else gemm_epilogue(p, acc, row0, col0, lane, fs);          // f32 output with a fused epilogue: direct form
   }
+  o.kstep = TRANS ? ld * 64 : 64;      // bytes per 32-deep stage
+}
+// stage t of the operand into `dst` (the operand's 8 KiB of a ring slot); kleft = kend - (kbeg + 32 t) > 0
+template <bool TRANS>
+__device__ __forceinline__ void rg_issue(const RgSrc& o, int t, int kleft, char* dst, int wave, int lane) {
+  const char* zero = reinterpret_cast<const char*>(g_rg_zero) + (lane & 3) * 16;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int blk = wave * 2 + i;
+    const char* src = o.base[i] + (size_t)t * o.kstep;
+    bool ok;
+    if (!TRANS) ok = o.kofs < kleft;
+    else ok = (blk * 4 + (lane >> 4)) < kleft && o.colok[i];
+    if (!ok) src = zero;
+    __builtin_amdgcn_global_load_lds((rg_glb_ptr)src, (rg_lds_ptr)(dst + blk * 1024), 16, 0, 0);
+  }
+}
+
+template <bool TB_KMAJOR, int FMT, bool GATE>
+__device__ __forceinline__ void gemm_ring_body(const GemmParams& p, const int bid, char* smem, const int ns) {
+  static_assert(!GATE || (FMT == 1 && TB_KMAJOR), "the fragment-side gate is the fp16 forward layout's");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int nwg = ntiles * p.splits;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int split = wg / ntiles, tile = wg - split * ntiles;
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg + 31) >> 5;
+
+  f4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  // the gate rows of this tile's images, fp16 [4][Kp] behind the ring (ordinary loads: requested first, so the counted waits below
+  // only ever see the LDS-DMA pieces as the youngest operations)
+  const int Kp = (p.K + 31) & ~31;
+  uint32_t gaddr[4] = {0, 0, 0, 0};
+  if (GATE) {
+    char* gl = smem + ns * RG_STG;
+    const int i0 = (int)fdiv((unsigned int)m0, p.xf_dhw);
+    const int nimg = (int)fdiv((unsigned int)min(m0 + BM - 1, p.M - 1), p.xf_dhw) - i0 + 1;
+    for (int e = tid * 8; e < 4 * Kp; e += 256 * 8) {
+      const int img = e / Kp, k = e - img * Kp;
+      h8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (img < nimg && k < p.K) {
+        const float* gp = p.xf_gate + (size_t)(i0 + img) * p.xf_C + k;
+        const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+        o = (h8){f2h(g0.x), f2h(g0.y), f2h(g0.z), f2h(g0.w), f2h(g1.x), f2h(g1.y), f2h(g1.z), f2h(g1.w)};
+      }
+      *reinterpret_cast<h8*>(gl + (size_t)e * 2) = o;
+    }
+    __syncthreads();         // the loop's bare s_barrier carries no wait for these stores
+    const uint32_t gl0 = (uint32_t)(uintptr_t)(lds_s4_ptr)gl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = min(m0 + wm * 64 + i * 16 + (lane & 15), p.M - 1);
+      const int li = (int)fdiv((unsigned int)r, p.xf_dhw) - i0;
+      gaddr[i] = gl0 + (uint32_t)((li * Kp + (lane >> 4) * 8) * 2);
+    }
+  }
+
+  RgSrc sa, sb;
+  rg_src_init<false>(sa, p.A, p.lda, m0, p.M, kbeg, wave, lane);
+  rg_src_init<!TB_KMAJOR>(sb, p.B, p.ldb, n0, p.N, kbeg, wave, lane);
+  const int klen = kend - kbeg;
+  for (int t = 0; t < ns; ++t) {
+    if (t < nk) {
+      rg_issue<false>(sa, t, klen - 32 * t, smem + t * RG_STG, wave, lane);
+      rg_issue<!TB_KMAJOR>(sb, t, klen - 32 * t, smem + t * RG_STG + 8192, wave, lane);
+    }
+  }
+  // fragment read addresses: A rows (lane & 15) of the wave's 64, 16-byte chunk (lane >> 4) ^ ((row >> 2) & 3); B alike, or transposed
+  // (read_frag<true>: k = 8 g + q, 16-column block cb = wn * 4 + j at ((cb ^ tr_key(k)) << 5): j enters through the XOR)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_s4_ptr)smem;
+  const uint32_t fo = (uint32_t)((lane & 15) * 64 + (((lane >> 4) ^ ((lane >> 2) & 3)) << 4));
+  const uint32_t a_rd = lds0 + wm * 4096 + fo;
+  const int tk = 8 * (lane >> 4) + ((lane >> 2) & 3);             // tr_key(tk) == tr_key(tk + 4): bit 2 is not part of the key
+  const uint32_t b_rd = TB_KMAJOR ? lds0 + 8192 + wn * 4096 + fo : lds0 + 8192 + (uint32_t)(tk * 256 + (lane & 3) * 8);
+  uint32_t b_tr[4] = {0, 0, 0, 0};
+  if (!TB_KMAJOR) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b_tr[j] = (uint32_t)(((wn * 4 + j) ^ tr_key(tk)) << 5);
+  }
+  bf8 af[2][4], bfr[2][4];
+  h8 gv[2][4];
+  // fragments (and gate chunks) of stage T from ring slot SLOT into register set SET
+#define RG_READ(SET, T, SLOT)                                                                                          \
+  {                                                                                                                    \
+    const uint32_t so = (uint32_t)(SLOT) * RG_STG;                                                                     \
+    af[SET][0] = rg_read_b128_off<0>(a_rd + so); af[SET][1] = rg_read_b128_off<1024>(a_rd + so);                       \
+    af[SET][2] = rg_read_b128_off<2048>(a_rd + so); af[SET][3] = rg_read_b128_off<3072>(a_rd + so);                    \
+    if (TB_KMAJOR) {                                                                                                   \
+      bfr[SET][0] = rg_read_b128_off<0>(b_rd + so); bfr[SET][1] = rg_read_b128_off<1024>(b_rd + so);                   \
+      bfr[SET][2] = rg_read_b128_off<2048>(b_rd + so); bfr[SET][3] = rg_read_b128_off<3072>(b_rd + so);                \
+    } else {                                                                                                           \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) bfr[SET][j] = rg_read_tr_off<0>(b_rd + so + b_tr[j]);              \
+    }                                                                                                                  \
+    if (GATE) {                                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) gv[SET][i] = __builtin_bit_cast(h8, rg_read_b128(gaddr[i] + (uint32_t)(T) * 64)); \
+    }                                                                                                                  \
+  }
+#define RG_WAIT(YOUNGER)                                                        \
+  {                                                                             \
+    const int y_ = (YOUNGER);                                                   \
+    if (y_ >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");              \
+    else if (y_ == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          \
+    else if (y_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       \
+  }
+  // One step: the MFMAs of stage t run on register set CUR while the fragments of stage t + 1 are read into set NXT behind them and
+  // stage t + NS is requested into the slot stage t has just left (its fragments are in registers, everybody's: the barrier).
+#define RG_STEP(CUR, NXT)                                                                                              \
+  {                                                                                                                    \
+    if (t + 1 < nk) RG_WAIT(min(ns - 2, nk - 2 - t))                  /* stage t + 1 landed (my pieces) */              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                /* set CUR complete */                            \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    int nslot = slot + 1; if (nslot == ns) nslot = 0;                                                                  \
+    if (t + 1 < nk) RG_READ(NXT, t + 1, nslot)                                                                         \
+    if (t + ns < nk) {                                                                                                 \
+      rg_issue<false>(sa, t + ns, klen - 32 * (t + ns), smem + slot * RG_STG, wave, lane);                             \
+      rg_issue<!TB_KMAJOR>(sb, t + ns, klen - 32 * (t + ns), smem + slot * RG_STG + 8192, wave, lane);                 \
+    }                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    if (GATE) {                                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) af[CUR][i] = __builtin_bit_cast(bf8, __builtin_bit_cast(h8, af[CUR][i]) * gv[CUR][i]); \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                    \
+        acc[i][j] = FMT == 1 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, bfr[CUR][j]), __builtin_bit_cast(h8, af[CUR][i]), acc[i][j], 0, 0, 0) \
+                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[CUR][j], af[CUR][i], acc[i][j], 0, 0, 0);   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    slot = nslot;                                                                                                      \
+  }
+  RG_WAIT(min(ns - 1, nk - 1))                 // stage 0 landed
+  __builtin_amdgcn_s_barrier();
+  RG_READ(0, 0, 0)
+  int slot = 0;
+  for (int t = 0; t < nk; t += 2) {
+    RG_STEP(0, 1)
+    if (t + 1 < nk) { ++t; RG_STEP(1, 0) --t; }
+  }
+#undef RG_STEP
+#undef RG_WAIT
+#undef RG_READ
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();           // every wave is past its last fragment read (and no DMA is in flight: the last wait was vmcnt(0))
+  gemm_tail<FMT>(p, acc, split == 0, tm, m0, n0, wm, wn, wave, lane, smem);
+}
+
+template <bool TB_KMAJOR, int FMT, bool GATE>
+__global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmParams p, int ns) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_ring_body<TB_KMAJOR, FMT, GATE>(p, blockIdx.x, smem, ns);
 }
 
 template <bool TA, bool TB_KMAJOR, int XF = 0, int FMT = 0>
@@ -306,11 +533,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 // rounded up to 8.  At 14 x 14 / 7 x 7 each of them alone runs 1.3-2.5 rounds of tiles on the chip; together the data
 // gradient's short blocks fill the tail of the weight gradient's long ones, and a layer issues one launch instead of two.
 template <int XF, int FMT1 = 0>      // FMT1: format of the weight-gradient product (2: its activation operand is fp16); the data gradient is bf16
-__global__ __launch_bounds__(256, 2) void gemm_bwd_pair_kernel(GemmParams p1, GemmParams p2, int nwg1, int n1r) {
+__global__ __launch_bounds__(256, 2) void gemm_bwd_pair_kernel(GemmParams p1, GemmParams p2, int nwg1, int n1r, int ns2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = blockIdx.x;
   if (bid < n1r) {
     if (bid < nwg1) gemm_body<true, false, XF, FMT1>(p1, bid, smem);
+  } else if (ns2) {                  // launch-uniform: the data gradient in the ring form (ring_stages)
+    gemm_ring_body<false, 0, false>(p2, bid - n1r, smem, ns2);
   } else {
     gemm_body<false, false, 0>(p2, bid - n1r, smem);
   }
@@ -333,6 +562,7 @@ struct GroupState { bool active = false; int n = 0; GroupItem item[2]; };
 static thread_local GroupState g_group;
 static int launch_generic(const GemmParams& p, int trans_a, int b_kmajor, int xf_operand, int nwg, hipStream_t s);
 static void generic_attr_optin();
+static int ring_stages(const GemmParams& p, int trans_a, int b_kmajor, int xf_operand, size_t* lds_bytes);
 
 static int group_flush() {
   GroupState& g = g_group;
@@ -348,10 +578,13 @@ static int group_flush() {
       const int n1r = (a.nwg + 7) & ~7;
       dim3 grid(n1r + b.nwg), block(256);
       const size_t lds = 2 * STAGE_BYTES;
-      if (a.xf == 2 && a.p.fmt == 2) hipLaunchKernelGGL((gemm_bwd_pair_kernel<2, 2>), grid, block, lds, s, a.p, b.p, a.nwg, n1r);
-      else if (a.xf == 2) hipLaunchKernelGGL((gemm_bwd_pair_kernel<2, 0>), grid, block, lds, s, a.p, b.p, a.nwg, n1r);
-      else if (a.p.fmt == 2) hipLaunchKernelGGL((gemm_bwd_pair_kernel<0, 2>), grid, block, lds, s, a.p, b.p, a.nwg, n1r);
-      else hipLaunchKernelGGL((gemm_bwd_pair_kernel<0, 0>), grid, block, lds, s, a.p, b.p, a.nwg, n1r);
+      size_t rl = 0;
+      int ns2 = ring_stages(b.p, 0, 0, 0, &rl);
+      if (rl > lds) ns2 = 0;
+      if (a.xf == 2 && a.p.fmt == 2) hipLaunchKernelGGL((gemm_bwd_pair_kernel<2, 2>), grid, block, lds, s, a.p, b.p, a.nwg, n1r, ns2);
+      else if (a.xf == 2) hipLaunchKernelGGL((gemm_bwd_pair_kernel<2, 0>), grid, block, lds, s, a.p, b.p, a.nwg, n1r, ns2);
+      else if (a.p.fmt == 2) hipLaunchKernelGGL((gemm_bwd_pair_kernel<0, 2>), grid, block, lds, s, a.p, b.p, a.nwg, n1r, ns2);
+      else hipLaunchKernelGGL((gemm_bwd_pair_kernel<0, 0>), grid, block, lds, s, a.p, b.p, a.nwg, n1r, ns2);
       return mmsim_check_launch("gemm_bwd_pair");
     }
   }
@@ -461,7 +694,54 @@ static void generic_attr_optin() {
   }
 }
 
+// Which products take the ring form, and with how many stages (0 = gemm_body): the forward layout (fp16 with an optional gate-only
+// operand transform, or bf16) and the data-gradient layout (bf16, B stored [K][N]), K a multiple of 8 and at least three stages deep.
+// MMSIM_GEMM_RING=0 sends everything to gemm_body (A/B runs).
+static int ring_stages(const GemmParams& p, int trans_a, int b_kmajor, int xf_operand, size_t* lds_bytes) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("MMSIM_GEMM_RING"); on = e ? atoi(e) : 1; }
+  if (!on || trans_a || (p.K % 8) || p.k_per_split < 96 || p.fmt == 2) return 0;
+  if (!b_kmajor && (p.fmt != 0 || xf_operand != 0)) return 0;
+  size_t gate = 0;
+  if (xf_operand == 1) {
+    if (p.xf_scale || !p.xf_gate || p.fmt != 1 || p.xf_hw < 43) return 0;       // <= 4 images per 128-row tile
+    gate = (size_t)4 * ((p.K + 31) & ~31) * 2;
+  } else if (xf_operand != 0) return 0;
+  const size_t epi = (size_t)4 * 64 * EP_PITCH * sizeof(float);
+  int ns = 4;
+  if (ns * RG_STG + gate > 80 * 1024) ns = 3;
+  if (ns * RG_STG + gate > 80 * 1024) return 0;
+  size_t b = ns * RG_STG + gate;
+  if (b < epi) b = epi;
+  *lds_bytes = b;
+  return ns;
+}
+static void ring_attr_optin() {
+  static unsigned long long done = 0;
+  const int dev = mmsim_current_device();
+  if ((done >> dev) & 1) return;
+  const int lds = 80 * 1024;
+  (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<true, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  done |= 1ull << dev;
+}
+
 static int launch_generic(const GemmParams& p, int trans_a, int b_kmajor, int xf_operand, int nwg, hipStream_t s) {
+  {
+    size_t rl = 0;
+    const int ns = ring_stages(p, trans_a, b_kmajor, xf_operand, &rl);
+    if (ns) {
+      ring_attr_optin();
+      dim3 grid(nwg), block(256);
+      if (!b_kmajor) hipLaunchKernelGGL((gemm_ring_kernel<false, 0, false>), grid, block, rl, s, p, ns);
+      else if (p.fmt == 1 && xf_operand == 1) hipLaunchKernelGGL((gemm_ring_kernel<true, 1, true>), grid, block, rl, s, p, ns);
+      else if (p.fmt == 1) hipLaunchKernelGGL((gemm_ring_kernel<true, 1, false>), grid, block, rl, s, p, ns);
+      else hipLaunchKernelGGL((gemm_ring_kernel<true, 0, false>), grid, block, rl, s, p, ns);
+      return mmsim_check_launch("gemm_ring");
+    }
+  }
   generic_attr_optin();
   const size_t lds = 2 * STAGE_BYTES;
   dim3 grid(nwg), block(256);
