@@ -229,9 +229,13 @@ def pick_split_k(M, N, K):
         while (t * (s + 1)) <= rounds * 256 and K // (s + 1) >= 512 and os.environ.get("MMSIM_SPLITK_EXACT", "1") != "0":
             s += 1
         return s * mult
+    # 128x128 generic kernel: every split adds a 64-KiB tile of fp32 ATOMICS (~1.3 TB/s chip-wide), so the count stops at ~192-384
+    # blocks, not at two full rounds of 512 (tools/bench_imgemm2.py, late-stage weight gradients of the image tower: 39 tiles x 16
+    # splits = 40 MB of atomics for a 1.8 MB gradient; halving the splits took the 20 late-stage blocks from 5.08 to 4.85 ms)
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     s = 1
-    while tiles * s < 512 and K // (s * 2) >= 512:
+    target = int(os.environ.get("MMSIM_SPLITK_TARGET", "192"))
+    while tiles * s < target and K // (s * 2) >= 512:
         s *= 2
     return s * mult
 

@@ -36,6 +36,7 @@ for cnt, H, cin, mid, cout in shapes:
     res = R(BF, P, cin)
     gw1, gw3 = torch.zeros(mid, cin, device="cuda"), torch.zeros(cout, mid, device="cuda")
     sk1, sk3 = ops.pick_split_k(mid, cin, P), ops.pick_split_k(cout, mid, P)
+    _d = int(os.environ.get('SK_DIV', '1')); sk1, sk3 = max(1, sk1 // _d), max(1, sk3 // _d)
     def f_exp(i): return lambda: lib.gemm_bf16_bnstats(0, P, mid, cin, x[i].data_ptr(), cin, w1.data_ptr(), cin, z1[i].data_ptr(), mid, None, None, None, 1, sums1.data_ptr(), scr.data_ptr(), scr.numel(), s)
     def f_prj(i): return lambda: lib.gemm_bf16_bnstats(1, P, cout, mid, a2[i].data_ptr(), mid, w3.data_ptr(), mid, z3[i].data_ptr(), cout, None, None, gate.data_ptr(), HW, sums3.data_ptr(), scr.data_ptr(), scr.numel(), s)
     def f_bprj(i):
