@@ -345,6 +345,16 @@ int mmsim_dwtile_bwd(const void* dy, const void* z2, const float* scale2, const 
                      const void* resid, const float* w_tap_major, void* out, float* sums1, float* g_tap_major,
                      float* dgamma2, float* dbeta2, int B, int H, int W, int C, int K, float* scratch,
                      unsigned long long scratch_floats, void* stream);
+/* mmsim_dwtile_bwd_s2 (round 4): the same one-kernel backward for the STRIDE-2 depthwise conv of an IR block (the first block of a
+ * stage: timm conv_dw with symmetric padding K/2 under cv_classifier.py:49).  H x W is the conv's INPUT plane (z1, out, sums1); dy, z2,
+ * gate, dsq and the depthwise BatchNorm's state live on the output plane ((H + 2 (K/2) - K) / 2 + 1 per side).  Replaces
+ * mmsim_bn_bwd_apply + mmsim_dwconv_bwd_weight(_xf) + mmsim_dwconv_bwd_data for those blocks. */
+int mmsim_dwtile_bwd_s2(const void* dy, const void* z2, const float* scale2, const float* shift2, const float* mean2,
+                        const float* rstd2, const float* sums2, const float* gate, const float* dsq, const void* z1,
+                        const float* scale1, const float* shift1, const float* mean1, const float* rstd1,
+                        const float* w_tap_major, void* out, float* sums1, float* g_tap_major,
+                        float* dgamma2, float* dbeta2, int B, int H, int W, int C, int K, float* scratch,
+                        unsigned long long scratch_floats, void* stream);
 
 /* The 5 x 5 stride-1 depthwise convolution on the matrix cores (csrc/dwmfma.hip, round 4): same contracts as mmsim_dwtile_fwd / _bwd
  * for K = 5, S = 1 (timm conv_dw of the k5 MBConv stages under cv_classifier.py:49), whole-plane tiles of 16 channels held PLANAR in

@@ -277,11 +277,17 @@ struct DwBwd {
 //   data    thread (u, strip of 4 centre pixels): da1 = sum_k dz2[q + PAD - k] w[k]; a1 = silu(bn(z1)) -> LDS (centre tile);
 //           dpre1 = da1 silu'(bn(z1)) -> HBM, with the expand BatchNorm's backward sums
 //   weight  thread (u, kernel row kh, row group): dW[kh][kw] += a1[q] dz2[q + PAD - k] over its rows (K x 8 accumulators)
-template <int K, bool PLAIN>
+// S = 2 (round 4; the first block of stages 2, 3, 4, 6 -- until now bn_bwd_apply + dwconv_bwd_weight(_xf) + dwconv_bwd_data, the
+// round-1 kernels: 8 passes over [pixels, mid] tensors, 2.0 ms per step): the same three phases with the CENTRE tile in INPUT space
+// (TH x TW input pixels, TH even, TW a multiple of 4, so tile origins are even) and the dz2 halo tile in OUTPUT space
+// ((TH/2 + 2) x (TW/2 + 2) output pixels from (oy0/2 - 1, ox0/2 - 1)).  Input pixel q meets output pixel o through tap k iff
+// q + PAD - k = 2 o: per dimension one tap (q + PAD even... ) or two/three -- the row parity is a runtime test per item, the column
+// parity is a compile-time one (strips start at multiples of 4), so the unrolled tap loops keep only the (K*K)/4 live taps per pixel.
+template <int K, bool PLAIN, int S = 1>
 __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int SW = 4, NQ = 4;                    // centre pixels per strip; staged pixels per trip
-  constexpr int NIN = SW + K - 1, PAD = K / 2;
+  constexpr int NIN = S == 1 ? SW + K - 1 : 4, PAD = K / 2;
   const int tid = threadIdx.x;
   const int u = tid % g.OG, pl = tid / g.OG;
   const bool lane_ok = pl < g.NP;
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
     fdivmod((unsigned int)t, g.d_tiles_img, b, ti);
     fdivmod((unsigned int)ti, g.d_tx, ty, tx);
     const int oy0 = ty * g.TH, ox0 = tx * g.TW;
-    const int iy0 = oy0 - PAD, ix0 = ox0 - PAD;
+    const int iy0 = S == 1 ? oy0 - PAD : (oy0 >> 1) - 1, ix0 = S == 1 ? ox0 - PAD : (ox0 >> 1) - 1;
     __syncthreads();
     // ---- stage: dz2 = scale (da - S1/P - zhat S2/P),  da = (dy gate + dsq/HW) silu'(scale z2 + shift)
     if (lane_ok) {
@@ -400,6 +406,28 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
           for (int e = 0; e < 8; ++e) da[j][e] = 0.f;
 #pragma unroll 1
         for (int kh = 0; kh < K; ++kh) {
+          if constexpr (S == 2) {
+            const int par = oy + PAD - kh;                    // = 2 (output row) - 2 (tile's first output row + 1)
+            if (par & 1) continue;
+            const uint4* row = tile + ((size_t)((par >> 1) + 1) * g.IW + sx * (SW / 2)) * g.OG + u;
+            uint4 raw[NIN];
+#pragma unroll
+            for (int x = 0; x < NIN; ++x) raw[x] = row[(size_t)x * g.OG];
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+              float w[8];
+              ldNf<8>(wl + ((kh * K + kw) * g.OG + u) * 8, w);
+#pragma unroll
+              for (int j = 0; j < SW; ++j) {
+                if ((j + PAD - kw) & 1) continue;             // compile time
+                float tv[8];
+                unpackN<8>(raw[((j + PAD - kw) >> 1) + 1], tv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) da[j][e] += tv[e] * w[e];
+              }
+            }
+            continue;
+          }
           const uint4* row = tile + ((size_t)(oy + K - 1 - kh) * g.IW + sx * SW) * g.OG + u;
 #if DWT_ROW_UNPACK
           float tt[NIN][8];
@@ -467,7 +495,33 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
     }
     __syncthreads();
     // ---- weight gradient
-    if (w_ok) {
+    if (S == 2 && w_ok) {      // centre rows of this thread's kernel row's parity only
+      for (int oy = ((PAD + wkh) & 1) + 2 * wrg; oy < g.TH; oy += 2 * p.RG) {
+        const uint4* arow = cen + (size_t)(oy * g.TW) * g.OG + wu;
+        const uint4* drow = tile + (size_t)((((oy + PAD - wkh) >> 1) + 1) * g.IW) * g.OG + wu;
+        for (int sx = 0; sx < g.nstrips; ++sx) {
+          uint4 ra[SW], rd[NIN];
+#pragma unroll
+          for (int j = 0; j < SW; ++j) ra[j] = arow[(size_t)(sx * SW + j) * g.OG];
+#pragma unroll
+          for (int x = 0; x < NIN; ++x) rd[x] = drow[(size_t)(sx * (SW / 2) + x) * g.OG];
+#pragma unroll
+          for (int j = 0; j < SW; ++j) {
+            float a[8];
+            unpack8h(ra[j], a);
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+              if ((j + PAD - kw) & 1) continue;               // compile time
+              float tv[8];
+              unpackN<8>(rd[((j + PAD - kw) >> 1) + 1], tv);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) dW[kw * 8 + e] += a[e] * tv[e];
+            }
+          }
+        }
+      }
+    }
+    if (S == 1 && w_ok) {
       for (int oy = wrg; oy < g.TH; oy += p.RG) {
         const uint4* arow = cen + (size_t)(oy * g.TW) * g.OG + wu;
         const uint4* drow = tile + (size_t)((oy + K - 1 - wkh) * g.IW) * g.OG + wu;
@@ -600,6 +654,44 @@ static int make_geom(DwTile* g, int B, int Hi, int Wi, int C, int K, int S, bool
   return MMSIM_OK;
 }
 
+// Stride-2 backward: the centre tile lives in INPUT space (TH even, TW a multiple of 4), the staged dz2 tile in output space
+// ((TH/2 + 2) x (TW/2 + 2)); DwTile's Ho / Wo stay the output plane, IH / IW the staged tile, tiles walk the input plane.
+static int make_geom_bwd2(DwTile* g, int B, int Hi, int Wi, int C, int K, size_t* lds, dim3* grid) {
+  MMSIM_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && C > 0 && (C % 8) == 0, "dwtile_bwd: bad geometry (C must be a multiple of 8)");
+  MMSIM_REQUIRE(K == 3 || K == 5, "dwtile_bwd: kernel 3 / 5 only");
+  g->B = B; g->Hi = Hi; g->Wi = Wi; g->C = C;
+  g->Ho = (Hi + 2 * (K / 2) - K) / 2 + 1; g->Wo = (Wi + 2 * (K / 2) - K) / 2 + 1;
+  const int units = C / 8;
+  g->OG = pick_og(units, 8);
+  while (g->OG * K > 256) g->OG /= 2;
+  g->NP = 256 / g->OG;
+  // tile: least (staged dy + z2 pixels, two tensors) + (z1 read + output written) per input pixel, under the LDS budget
+  double best = 1e30;
+  g->TH = 2; g->TW = 4;
+  for (int TW = 4; TW <= ((Wi + 3) & ~3) && TW <= 32; TW += 4)
+    for (int TH = 2; TH <= ((Hi + 1) & ~1) && TH <= 32; TH += 2) {
+      const int IH = TH / 2 + 2, IW = TW / 2 + 2;
+      const long need = ((long)IH * IW + (long)TH * TW) * g->OG * 16 + (long)K * K * g->OG * 32;
+      if (need > 72 * 1024) break;
+      const int tx = (Wi + TW - 1) / TW, ty = (Hi + TH - 1) / TH;
+      const double cost = ((double)tx * ty * (2.0 * IH * IW + 2.0 * TH * TW)) / ((double)Hi * Wi);
+      if (cost < best - 1e-9) { best = cost; g->TH = TH; g->TW = TW; }
+    }
+  g->IH = g->TH / 2 + 2; g->IW = g->TW / 2 + 2;
+  g->nstrips = g->TW / 4;
+  const int tx = (Wi + g->TW - 1) / g->TW, ty = (Hi + g->TH - 1) / g->TH;
+  g->total_tiles = B * tx * ty;
+  const int gy = (units + g->OG - 1) / g->OG;
+  int want = 2048 / gy; if (want < 1) want = 1;
+  g->tiles_per_block = (g->total_tiles + want - 1) / want;
+  g->d_tiles_img = make_fastdiv(tx * ty); g->d_tx = make_fastdiv(tx); g->d_iw = make_fastdiv(g->IW); g->d_strips = make_fastdiv(g->nstrips);
+  const size_t need = ((size_t)g->IH * g->IW + (size_t)g->TH * g->TW) * g->OG * 16 + (size_t)K * K * g->OG * 32;
+  const size_t red = 256 * 16 * sizeof(float);
+  *lds = need > red ? need : red;
+  *grid = dim3((g->total_tiles + g->tiles_per_block - 1) / g->tiles_per_block, gy);
+  return MMSIM_OK;
+}
+
 // more than 64 KiB of dynamic LDS needs the per-(function, device) opt-in
 static void optin_bwd_lds() {
   static unsigned long long done = 0;
@@ -610,6 +702,8 @@ static void optin_bwd_lds() {
   (void)hipFuncSetAttribute((const void*)dwt_bwd_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
   (void)hipFuncSetAttribute((const void*)dwt_bwd_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
   (void)hipFuncSetAttribute((const void*)dwt_bwd_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  (void)hipFuncSetAttribute((const void*)dwt_bwd_kernel<3, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  (void)hipFuncSetAttribute((const void*)dwt_bwd_kernel<5, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
   done |= 1ull << dev;
 }
 
@@ -633,19 +727,21 @@ extern "C" int mmsim_dwtile_fwd(const void* in, const float* xf_scale, const flo
   return mmsim_check_launch("dwtile_fwd");
 }
 
-extern "C" int mmsim_dwtile_bwd(const void* dy, const void* z2, const float* scale2, const float* shift2, const float* mean2,
-                                const float* rstd2, const float* sums2, const float* gate, const float* dsq, const void* z1,
-                                const float* scale1, const float* shift1, const float* mean1, const float* rstd1,
-                                const void* resid, const float* w_tap_major, void* out, float* sums1, float* g_tap_major,
-                                float* dgamma2, float* dbeta2, int B, int H, int W, int C, int K, float* scratch,
-                                unsigned long long scratch_floats, void* stream) {
+static int dwtile_bwd_impl(const void* dy, const void* z2, const float* scale2, const float* shift2, const float* mean2,
+                           const float* rstd2, const float* sums2, const float* gate, const float* dsq, const void* z1,
+                           const float* scale1, const float* shift1, const float* mean1, const float* rstd1,
+                           const void* resid, const float* w_tap_major, void* out, float* sums1, float* g_tap_major,
+                           float* dgamma2, float* dbeta2, int B, int H, int W, int C, int K, int S, float* scratch,
+                           unsigned long long scratch_floats, void* stream) {
   MMSIM_REQUIRE(dy && z2 && scale2 && shift2 && mean2 && rstd2 && sums2 && gate && dsq && z1 && w_tap_major && out && g_tap_major &&
                     dgamma2 && dbeta2 && scratch, "dwtile_bwd: null operand");
   const bool plain = scale1 == nullptr;
   MMSIM_REQUIRE(plain ? (!shift1 && !mean1 && !rstd1) : (shift1 && mean1 && rstd1 && sums1 && !resid),
                 "dwtile_bwd: the expand BatchNorm state comes as a whole (IR block, no resid) or not at all (DS block)");
+  MMSIM_REQUIRE(S == 1 || (S == 2 && !plain), "dwtile_bwd: stride 1, or stride 2 for an IR block (expand BatchNorm state given)");
   DwTile g; size_t lds; dim3 grid;
-  int rc = make_geom(&g, B, H, W, C, K, 1, true, true, &lds, &grid); if (rc) return rc;
+  int rc = S == 1 ? make_geom(&g, B, H, W, C, K, 1, true, true, &lds, &grid) : make_geom_bwd2(&g, B, H, W, C, K, &lds, &grid);
+  if (rc) return rc;
   const size_t n_bn = plain ? 0 : (size_t)grid.x * 2 * C, n_w = (size_t)grid.x * K * K * C;
   MMSIM_REQUIRE(scratch_floats >= (unsigned long long)(n_bn + n_w), "dwtile_bwd: scratch too small");
   DwBwd p;
@@ -653,18 +749,43 @@ extern "C" int mmsim_dwtile_bwd(const void* dy, const void* z2, const float* sca
   p.sc2 = scale2; p.sh2 = shift2; p.mu2 = mean2; p.rs2 = rstd2; p.sums2 = sums2; p.gate = gate; p.dsq = dsq;
   p.sc1 = scale1; p.sh1 = shift1; p.mu1 = mean1; p.rs1 = rstd1; p.wT = w_tap_major; p.out = (bf16*)out;
   p.parts_bn = scratch; p.parts_w = scratch + n_bn; p.dgamma2 = dgamma2; p.dbeta2 = dbeta2;
-  p.invP = 1.0f / (float)((size_t)B * H * W); p.inv_hw = 1.0f / (float)(H * W);
+  p.invP = 1.0f / (float)((size_t)B * g.Ho * g.Wo); p.inv_hw = 1.0f / (float)(g.Ho * g.Wo);      // the depthwise BatchNorm's / the SE pool's plane
   p.RG = 256 / (g.OG * K); if (p.RG < 1) p.RG = 1;
   MMSIM_REQUIRE(g.OG * K <= 256, "dwtile_bwd: channel group too wide for the weight-gradient mapping");
   hipStream_t s = (hipStream_t)stream;
   optin_bwd_lds();
 #define DWT_B(KK, PP) hipLaunchKernelGGL((dwt_bwd_kernel<KK, PP>), grid, dim3(256), lds, s, p, g)
-  if (K == 3) { if (plain) DWT_B(3, true); else DWT_B(3, false); }
+  if (S == 2) {
+    if (K == 3) hipLaunchKernelGGL((dwt_bwd_kernel<3, false, 2>), grid, dim3(256), lds, s, p, g);
+    else hipLaunchKernelGGL((dwt_bwd_kernel<5, false, 2>), grid, dim3(256), lds, s, p, g);
+  }
+  else if (K == 3) { if (plain) DWT_B(3, true); else DWT_B(3, false); }
   else { if (plain) DWT_B(5, true); else DWT_B(5, false); }
 #undef DWT_B
   if (!plain) mmsim_launch_reduce2(p.parts_bn, 2 * C, sums1, p.parts_w, K * K * C, g_tap_major, grid.x, s);      // both slabs, one launch
   else mmsim_launch_reduce(p.parts_w, grid.x, K * K * C, g_tap_major, 1, s);
   return mmsim_check_launch("dwtile_bwd");
+}
+
+extern "C" int mmsim_dwtile_bwd(const void* dy, const void* z2, const float* scale2, const float* shift2, const float* mean2,
+                                const float* rstd2, const float* sums2, const float* gate, const float* dsq, const void* z1,
+                                const float* scale1, const float* shift1, const float* mean1, const float* rstd1,
+                                const void* resid, const float* w_tap_major, void* out, float* sums1, float* g_tap_major,
+                                float* dgamma2, float* dbeta2, int B, int H, int W, int C, int K, float* scratch,
+                                unsigned long long scratch_floats, void* stream) {
+  return dwtile_bwd_impl(dy, z2, scale2, shift2, mean2, rstd2, sums2, gate, dsq, z1, scale1, shift1, mean1, rstd1, resid, w_tap_major, out,
+                         sums1, g_tap_major, dgamma2, dbeta2, B, H, W, C, K, 1, scratch, scratch_floats, stream);
+}
+// The same fused backward for a STRIDE-2 depthwise conv of an IR block: H x W is the conv's INPUT plane (z1, out), dy / z2 / gate / dsq
+// live on the output plane ((H + 2 (K/2) - K) / 2 + 1 squared: timm's symmetric padding, cv_classifier.py:49).
+extern "C" int mmsim_dwtile_bwd_s2(const void* dy, const void* z2, const float* scale2, const float* shift2, const float* mean2,
+                                   const float* rstd2, const float* sums2, const float* gate, const float* dsq, const void* z1,
+                                   const float* scale1, const float* shift1, const float* mean1, const float* rstd1,
+                                   const float* w_tap_major, void* out, float* sums1, float* g_tap_major,
+                                   float* dgamma2, float* dbeta2, int B, int H, int W, int C, int K, float* scratch,
+                                   unsigned long long scratch_floats, void* stream) {
+  return dwtile_bwd_impl(dy, z2, scale2, shift2, mean2, rstd2, sums2, gate, dsq, z1, scale1, shift1, mean1, rstd1, nullptr, w_tap_major, out,
+                         sums1, g_tap_major, dgamma2, dbeta2, B, H, W, C, K, 2, scratch, scratch_floats, stream);
 }
 
 // ================================================================= fused backward of the expand stage (early MBConv blocks)

@@ -85,6 +85,8 @@ _DW5M = os.environ.get("MMSIM_DW5M", "1") != "0"
 # at least 14 x 14: 379 vs 401 us at 28^2 x 336, 270 vs 335 us at 14^2 x 960; at 7^2 x 1632 it is 172 vs 151 us and stays off), 2: every
 # eligible shape, 0: never
 _DW5M_BWD = int(os.environ.get("MMSIM_DW5M_BWD", "1"))
+# MMSIM_DWT_BWD_S2=0: the stride-2 blocks' depthwise backward as the round-1 kernels (bn_bwd_apply + dwconv_bwd_weight_xf + dwconv_bwd_data)
+_DWT_BWD_S2 = os.environ.get("MMSIM_DWT_BWD_S2", "1") != "0"
 # MMSIM_PW_FUSED=0: expand-stage backward as bn_bwd + two GEMMs instead of the one-pass mmsim_pw_expand_bwd (A/B switch)
 _PW_FUSED = os.environ.get("MMSIM_PW_FUSED", "1") != "0"
 # MMSIM_PW_PROJECT=0: projection conv of the early stages through the generic GEMM instead of the streaming kernels (A/B switch)
@@ -585,8 +587,19 @@ class EfficientNet(nn.Module):
         if not hasattr(st, "gT_all"):
             self._zero_gT(st)
         gT = st.gT_all[st.gT_off[n]:st.gT_off[n] + b.k * b.k * b.mid]
-        fused = _DWTILE and b.stride == 1
-        if fused:
+        fused = _DWTILE and (b.stride == 1 or (_DWT_BWD_S2 and b.type == "ir"))
+        if fused and b.stride == 2:
+            # the stride-2 form of the same kernel (round 4): the centre tile in input space, dz2 staged on the output plane
+            bnp = lambda nm, i: self._bnp(st, nm, i).data_ptr()
+            dn, en = n + "." + d_bn, n + "." + e_bn
+            dpre1 = E(P_in, b.mid)
+            lib.dwtile_bwd_s2(da2g.data_ptr(), bs.z2.data_ptr(), bnp(dn, 2), bnp(dn, 3), bnp(dn, 0), bnp(dn, 1),
+                              self._sums(st, dn, "b").data_ptr(), bs.gate.data_ptr(), ds.data_ptr(),
+                              bs.z1.data_ptr(), bnp(en, 2), bnp(en, 3), bnp(en, 0), bnp(en, 1), bs.wT.data_ptr(),
+                              dpre1.data_ptr(), self._sums(st, en, "b").data_ptr(), gT.data_ptr(), G(dn + ".weight").data_ptr(),
+                              G(dn + ".bias").data_ptr(), B, Hn, Wn, b.mid, b.k, *self._scr(), s)
+            del da2g
+        elif fused:
             # ONE kernel: depthwise-BN + SiLU + gate backward (on the way into LDS), depthwise data and weight gradients,
             # expand-BN + SiLU backward on the way out (mmsim_dwtile_bwd)
             bnp = lambda nm, i: self._bnp(st, nm, i).data_ptr()

@@ -24,7 +24,7 @@ DEV = "cuda"
 NAME = "efficientnet_b4"
 # entry points whose use at 224^2 is asserted (forward, then backward)
 STREAMING = ("pw_expand_fwd", "pw_project_fwd_xf", "pw_project_fwd", "dwtile_fwd", "dw5m_fwd", "pw_project_bwd_xf", "pw_expand_bwd", "dwtile_bwd",
-             "dw5m_bwd")
+             "dw5m_bwd", "dwtile_bwd_s2")
 
 
 class _Counter:
@@ -102,6 +102,7 @@ def test_b4_at_224_conditioned_eval_and_train_match_the_oracle():
     assert cnt.n["pw_expand_fwd"] >= 6 and cnt.n["pw_project_fwd_xf"] + cnt.n["pw_project_fwd"] >= 12, cnt.n
     assert cnt.n["pw_project_bwd_xf"] >= 5 and cnt.n["pw_expand_bwd"] >= 8, cnt.n
     assert cnt.n["dwtile_bwd"] + cnt.n["dw5m_bwd"] >= 28 and cnt.n["dwtile_fwd"] + cnt.n["dw5m_fwd"] >= 56 and cnt.n["dw5m_fwd"] == 32, cnt.n
+    assert cnt.n["dwtile_bwd_s2"] == 4, cnt.n          # the first block of the four stride-2 stages: the fused kernel, not the round-1 trio
     assert cnt.n["dw5m_bwd"] == 9, cnt.n               # the 28^2 and 14^2 5 x 5 blocks (3 + 6); the 7^2 ones stay on the VALU kernel (measured faster there)
     named = dict(model.named_parameters())
     gmax = max(v.norm().item() for v in grads.values())
