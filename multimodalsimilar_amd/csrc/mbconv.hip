@@ -31,8 +31,31 @@ struct DwTile {
   int TH, TW, IH, IW;                 // output tile; staged input tile (with halo)
   int total_tiles, tiles_per_block;   // B * tiles per image; consecutive tiles walked by one block
   int OG, NP, nstrips;                // channel units per block, pixel lanes (256 / OG), TW / 4
+  int gx, gy;                         // logical grid: tile ranges x channel groups (see dwt_block_id)
   FastDiv d_tiles_img, d_tx, d_iw, d_strips;
 };
+
+// 1-D launch of gx x gy logical blocks (tile range bx, channel group by).  With a 2-D grid the channel groups of one tile range ran
+// half a kernel apart, and when a group's bytes per pixel are not whole cache lines (C = 144: two groups of 144 B in 288-B pixels)
+// every line was fetched from HBM twice (profiles/r04_pmc_image_tower.json: dwt_fwd<3,2> 1.79 x its algorithmic bytes).  Here the
+// groups of a tile range are CONSECUTIVE IN ONE XCD (block id % 8 = XCD, id / 8 = its launch slot): the second reader hits that L2.
+#ifndef DWT_GRID_2D
+#define DWT_GRID_2D 0
+#endif
+__device__ __forceinline__ bool dwt_block_id(const DwTile& g, int& bx, int& by) {
+#if DWT_GRID_2D          // A/B builds only (tools/build_variant.sh): the order of the former 2-D grid, x fastest
+  by = blockIdx.x / g.gx; bx = blockIdx.x % g.gx;
+  return by < g.gy;
+#endif
+  const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+  by = j % g.gy;
+  bx = (j / g.gy) * 8 + xcd;
+  return bx < g.gx;
+}
+static dim3 dwt_grid(DwTile* g, int gx, int gy) {
+  g->gx = gx; g->gy = gy;
+  return dim3(((gx + 7) / 8) * 8 * gy);
+}
 
 template <int CPT> struct UnitT;
 template <> struct UnitT<8> { typedef uint4 T; };
@@ -122,9 +145,11 @@ __global__ __launch_bounds__(256, 3) void dwt_fwd_kernel(const f16* in, const fl
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PAD = K / 2, NIN = 3 * S + K;
   const int tid = threadIdx.x;
+  int bx, by;
+  if (!dwt_block_id(g, bx, by)) return;
   const int u = tid % g.OG, pl = tid / g.OG;
   const bool lane_ok = pl < g.NP;
-  const int unit = blockIdx.y * g.OG + u;
+  const int unit = by * g.OG + u;
   const bool cok = lane_ok && unit * 8 < g.C;
   const int c0 = cok ? unit * 8 : 0;
   const int npix = g.IH * g.IW;
@@ -132,13 +157,13 @@ __global__ __launch_bounds__(256, 3) void dwt_fwd_kernel(const f16* in, const fl
   float* wl = reinterpret_cast<float*>(smem + (size_t)npix * g.OG * 16);       // [tap][OG][8] weights of this channel group
   for (int i = tid; i < K * K * g.OG * 8; i += 256) {
     const int tap = i / (g.OG * 8), r = i - tap * (g.OG * 8);
-    const int c = blockIdx.y * g.OG * 8 + r;
+    const int c = by * g.OG * 8 + r;
     wl[i] = c < g.C ? wT[(size_t)tap * g.C + c] : 0.f;
   }
   float st[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) st[i] = 0.f;
-  const int t0 = blockIdx.x * g.tiles_per_block, t1 = min(g.total_tiles, t0 + g.tiles_per_block);
+  const int t0 = bx * g.tiles_per_block, t1 = min(g.total_tiles, t0 + g.tiles_per_block);
   for (int t = t0; t < t1; ++t) {
     int b, ti, ty, tx;
     fdivmod((unsigned int)t, g.d_tiles_img, b, ti);
@@ -247,7 +272,7 @@ __global__ __launch_bounds__(256, 3) void dwt_fwd_kernel(const f16* in, const fl
   }
   lanes_reduce<16, 16>(st, reinterpret_cast<float*>(smem), u, pl, g.OG, g.NP);
   if (cok && pl == 0) {
-    float* slab = parts + (size_t)blockIdx.x * 2 * g.C + c0;
+    float* slab = parts + (size_t)bx * 2 * g.C + c0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { slab[e] = st[e]; slab[g.C + e] = st[8 + e]; }
   }
@@ -289,9 +314,11 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
   constexpr int SW = 4, NQ = 4;                    // centre pixels per strip; staged pixels per trip
   constexpr int NIN = S == 1 ? SW + K - 1 : 4, PAD = K / 2;
   const int tid = threadIdx.x;
+  int bx, by;
+  if (!dwt_block_id(g, bx, by)) return;
   const int u = tid % g.OG, pl = tid / g.OG;
   const bool lane_ok = pl < g.NP;
-  const int unit = blockIdx.y * g.OG + u;
+  const int unit = by * g.OG + u;
   const bool cok = lane_ok && unit * 8 < g.C;
   const int c0 = cok ? unit * 8 : 0;
   const int npix = g.IH * g.IW, ncen = g.TH * g.TW;
@@ -300,23 +327,23 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
   float* wl = reinterpret_cast<float*>(smem + (size_t)(npix + ncen) * g.OG * 16);          // [tap][OG][8]
   for (int i = tid; i < K * K * g.OG * 8; i += 256) {
     const int tap = i / (g.OG * 8), r = i - tap * (g.OG * 8);
-    const int c = blockIdx.y * g.OG * 8 + r;
+    const int c = by * g.OG * 8 + r;
     wl[i] = c < g.C ? p.wT[(size_t)tap * g.C + c] : 0.f;
   }
-  if (blockIdx.x == 0 && cok && pl == 0) {            // dgamma += sum da zhat, dbeta += sum da (the BN-backward sums themselves)
+  if (bx == 0 && cok && pl == 0) {            // dgamma += sum da zhat, dbeta += sum da (the BN-backward sums themselves)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { p.dgamma2[c0 + e] += p.sums2[g.C + c0 + e]; p.dbeta2[c0 + e] += p.sums2[c0 + e]; }
   }
   // weight-phase mapping: thread -> (unit wu, kernel row wkh, row group wrg)
   const int wu = tid % g.OG, wrest = tid / g.OG;
   const int wkh = wrest % K, wrg = wrest / K;
-  const bool w_ok = wrg < p.RG && (blockIdx.y * g.OG + wu) * 8 < g.C;
+  const bool w_ok = wrg < p.RG && (by * g.OG + wu) * 8 < g.C;
   float st[16], dW[K * 8];
 #pragma unroll
   for (int i = 0; i < 16; ++i) st[i] = 0.f;
 #pragma unroll
   for (int i = 0; i < K * 8; ++i) dW[i] = 0.f;
-  const int t0 = blockIdx.x * g.tiles_per_block, t1 = min(g.total_tiles, t0 + g.tiles_per_block);
+  const int t0 = bx * g.tiles_per_block, t1 = min(g.total_tiles, t0 + g.tiles_per_block);
   for (int t = t0; t < t1; ++t) {
     int b, ti, ty, tx;
     fdivmod((unsigned int)t, g.d_tiles_img, b, ti);
@@ -566,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
   if (!PLAIN) {
     lanes_reduce<16, 16>(st, red, u, pl, g.OG, g.NP);
     if (cok && pl == 0) {
-      float* slab = p.parts_bn + (size_t)blockIdx.x * 2 * g.C + c0;
+      float* slab = p.parts_bn + (size_t)bx * 2 * g.C + c0;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { slab[e] = st[e]; slab[g.C + e] = st[8 + e]; }
     }
@@ -585,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void dwt_bwd_kernel(DwBwd p, DwTile g) {
       for (int r = 1; r < p.RG; ++r)
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] += red[(((r * K + wkh) * g.OG) + wu) * 8 + e];
-      float* slab = p.parts_w + (size_t)blockIdx.x * K * K * g.C + (size_t)(wkh * K + kw) * g.C + (blockIdx.y * g.OG + wu) * 8;
+      float* slab = p.parts_w + (size_t)bx * K * K * g.C + (size_t)(wkh * K + kw) * g.C + (by * g.OG + wu) * 8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) slab[e] = a[e];
     }
@@ -650,7 +677,7 @@ static int make_geom(DwTile* g, int B, int Hi, int Wi, int C, int K, int S, bool
   size_t need = ((size_t)g->IH * g->IW + (bwd ? (size_t)g->TH * g->TW : 0)) * g->OG * 16 + (size_t)K * K * g->OG * 32;
   const size_t red = 256 * 16 * sizeof(float);            // the end-of-block reductions reuse the tile region
   *lds = need > red ? need : red;
-  *grid = dim3((g->total_tiles + g->tiles_per_block - 1) / g->tiles_per_block, gy);
+  *grid = dwt_grid(g, (g->total_tiles + g->tiles_per_block - 1) / g->tiles_per_block, gy);
   return MMSIM_OK;
 }
 
@@ -688,7 +715,7 @@ static int make_geom_bwd2(DwTile* g, int B, int Hi, int Wi, int C, int K, size_t
   const size_t need = ((size_t)g->IH * g->IW + (size_t)g->TH * g->TW) * g->OG * 16 + (size_t)K * K * g->OG * 32;
   const size_t red = 256 * 16 * sizeof(float);
   *lds = need > red ? need : red;
-  *grid = dim3((g->total_tiles + g->tiles_per_block - 1) / g->tiles_per_block, gy);
+  *grid = dwt_grid(g, (g->total_tiles + g->tiles_per_block - 1) / g->tiles_per_block, gy);
   return MMSIM_OK;
 }
 
@@ -714,7 +741,7 @@ extern "C" int mmsim_dwtile_fwd(const void* in, const float* xf_scale, const flo
   MMSIM_REQUIRE((xf_scale == nullptr) == (xf_shift == nullptr), "dwtile_fwd: scale and shift come together");
   DwTile g; size_t lds; dim3 grid;
   int rc = make_geom(&g, B, Hi, Wi, C, K, S, false, xf_scale != nullptr, &lds, &grid); if (rc) return rc;
-  MMSIM_REQUIRE(scratch_floats >= (unsigned long long)grid.x * 2 * C, "dwtile_fwd: scratch too small");
+  MMSIM_REQUIRE(scratch_floats >= (unsigned long long)g.gx * 2 * C, "dwtile_fwd: scratch too small");
   hipStream_t s = (hipStream_t)stream;
 #define DWT_F(KK, SS, XX) hipLaunchKernelGGL((dwt_fwd_kernel<KK, SS, XX>), grid, dim3(256), lds, s, (const f16*)in, xf_scale, xf_shift, w_tap_major, (f16*)z, scratch, g)
 #define DWT_FX(XX)                                                                        \
@@ -723,7 +750,7 @@ extern "C" int mmsim_dwtile_fwd(const void* in, const float* xf_scale, const flo
   if (xf_scale) { DWT_FX(true) } else { DWT_FX(false) }
 #undef DWT_FX
 #undef DWT_F
-  mmsim_launch_reduce(scratch, grid.x, 2 * C, sums, 1, s);      /* sums += (pre-zeroed by the caller) */
+  mmsim_launch_reduce(scratch, g.gx, 2 * C, sums, 1, s);      /* sums += (pre-zeroed by the caller) */
   return mmsim_check_launch("dwtile_fwd");
 }
 
@@ -742,7 +769,7 @@ static int dwtile_bwd_impl(const void* dy, const void* z2, const float* scale2, 
   DwTile g; size_t lds; dim3 grid;
   int rc = S == 1 ? make_geom(&g, B, H, W, C, K, 1, true, true, &lds, &grid) : make_geom_bwd2(&g, B, H, W, C, K, &lds, &grid);
   if (rc) return rc;
-  const size_t n_bn = plain ? 0 : (size_t)grid.x * 2 * C, n_w = (size_t)grid.x * K * K * C;
+  const size_t n_bn = plain ? 0 : (size_t)g.gx * 2 * C, n_w = (size_t)g.gx * K * K * C;
   MMSIM_REQUIRE(scratch_floats >= (unsigned long long)(n_bn + n_w), "dwtile_bwd: scratch too small");
   DwBwd p;
   p.dy = (const bf16*)dy; p.z2 = (const f16*)z2; p.z1 = (const f16*)z1; p.resid = (const bf16*)resid;
@@ -762,8 +789,8 @@ static int dwtile_bwd_impl(const void* dy, const void* z2, const float* scale2, 
   else if (K == 3) { if (plain) DWT_B(3, true); else DWT_B(3, false); }
   else { if (plain) DWT_B(5, true); else DWT_B(5, false); }
 #undef DWT_B
-  if (!plain) mmsim_launch_reduce2(p.parts_bn, 2 * C, sums1, p.parts_w, K * K * C, g_tap_major, grid.x, s);      // both slabs, one launch
-  else mmsim_launch_reduce(p.parts_w, grid.x, K * K * C, g_tap_major, 1, s);
+  if (!plain) mmsim_launch_reduce2(p.parts_bn, 2 * C, sums1, p.parts_w, K * K * C, g_tap_major, g.gx, s);      // both slabs, one launch
+  else mmsim_launch_reduce(p.parts_w, g.gx, K * K * C, g_tap_major, 1, s);
   return mmsim_check_launch("dwtile_bwd");
 }
 
