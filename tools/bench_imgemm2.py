@@ -51,6 +51,13 @@ for cnt, H, cin, mid, cout in shapes:
                 ops.gemm(dz1[i], x[i], gw1, trans_a=True, b_kmajor=False, split_k=sk1, accumulate=True)
                 ops.gemm(dz1[i], w1b, dx[i], b_kmajor=False, epilogue=ops.EPI_ADD, aux_in=res)
         return g
+    if os.environ.get("SPLIT_PAIRS"):      # the two members of each backward pair on their own (no paired launch)
+        def f_w3(i): return lambda: lib.gemm_bf16_xf(2, cout, mid, P, dz3[i].data_ptr(), cout, a2[i].data_ptr(), mid, gw3.data_ptr(), mid, 1, None, None, gate.data_ptr(), HW, sk3, 1, s)
+        def f_d3(i): return lambda: ops.gemm(dz3[i], w3b, da[i], b_kmajor=False)
+        def f_w1(i): return lambda: ops.gemm(dz1[i], x[i], gw1, trans_a=True, b_kmajor=False, split_k=sk1, accumulate=True)
+        def f_d1(i): return lambda: ops.gemm(dz1[i], w1b, dx[i], b_kmajor=False, epilogue=ops.EPI_ADD, aux_in=res)
+        print(f"   {H:2d}^2 {cin}->{mid}->{cout}: wgrad-project(sk={sk3}) {t([f_w3(i) for i in range(NSET)]):6.1f} | dgrad-project {t([f_d3(i) for i in range(NSET)]):6.1f} | "
+              f"wgrad-expand(sk={sk1}) {t([f_w1(i) for i in range(NSET)]):6.1f} | dgrad-expand {t([f_d1(i) for i in range(NSET)]):6.1f} us", flush=True)
     row = []
     for nm, mk, by in (("expand", f_exp, (P * cin + P * mid) * 2), ("project", f_prj, (P * mid + P * cout) * 2),
                        ("bwd-project", f_bprj, (2 * P * cout + 2 * P * mid) * 2), ("bwd-expand", f_bexp, (2 * P * mid + 3 * P * cin) * 2)):
