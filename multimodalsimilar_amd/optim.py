@@ -70,10 +70,44 @@ class FusedAdamW(torch.optim.Optimizer):
         for f in self.flats:
             f.zero_grad(lazy=lazy)
 
+    def _moments(self, f):
+        mv = self._mv.get(id(f))
+        if mv is None or mv[0].device != f.master.device:
+            mv = (torch.zeros_like(f.master), torch.zeros_like(f.master))
+            self._mv[id(f)] = mv
+        return mv
+
+    def _update(self, f, lo, hi):
+        """The AdamW launch for elements [lo, hi) of flat buffer f (step count self._t), on the current stream."""
+        g = self.param_groups[0]
+        mv = self._moments(f)
+        rn = self._row_owners.get(id(f))
+        rows = rn.adamw_row_buffers() if rn is not None else None
+        if rows is not None:
+            # a row-normalised weight matrix (the ArcFace head): the update also leaves F.normalize(weight) for the next forward
+            if lo != 0 or hi != f.total:
+                raise ValueError("FusedAdamW: a row-normalised buffer is updated as a whole")
+            R, D, w_hat, inv_norm = rows
+            n = R * D
+            ops.adamw_rows_l2norm(f.master[:n].view(R, D), f.grad[:n].view(R, D), mv[0][:n].view(R, D), mv[1][:n].view(R, D),
+                                  w_hat, inv_norm, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._t,
+                                  self.grad_scale, dev_hyper=self.dev_hyper)
+            rn.mark_normalised()
+            return
+        ops.adamw_step(f.master[lo:hi], f.grad[lo:hi], mv[0][lo:hi], mv[1][lo:hi], f.shadow[lo:hi], g["lr"], g["betas"][0], g["betas"][1],
+                       g["eps"], g["weight_decay"], self._t, self.grad_scale, dev_hyper=self.dev_hyper,
+                       shadow16=None if f.shadow16 is None else f.shadow16[lo:hi])
+        if rn is not None:
+            rn.invalidate_normalised()          # the master changed under the module: its cached w_hat is stale
+
     @torch.no_grad()
     def step(self, closure=None):
-        g = self.param_groups[0]
         self._t += 1
+        self._finish({})
+        return None
+
+    def _finish(self, done):
+        """Update every element of every buffer that ``done`` ({id(flat): [(lo, hi), ...]}) does not cover."""
         if self.flats[0].master.is_cuda:
             ops.join_side_streams()      # gradients written by a tower on its own stream (multimodal_classifier.py)
         for f in self.flats:
@@ -81,27 +115,33 @@ class FusedAdamW(torch.optim.Optimizer):
                 continue          # never produced a gradient: skipped like torch skips grad-is-None params
             f.ensure_device_state()
             f.materialize_zero()          # lazily zeroed and never written since: the update must see zeros
-            mv = self._mv.get(id(f))
-            if mv is None or mv[0].device != f.master.device:
-                mv = (torch.zeros_like(f.master), torch.zeros_like(f.master))
-                self._mv[id(f)] = mv
-            rn = self._row_owners.get(id(f))
-            rows = rn.adamw_row_buffers() if rn is not None else None
-            if rows is not None:
-                # a row-normalised weight matrix (the ArcFace head): the update also leaves F.normalize(weight) for the next forward
-                R, D, w_hat, inv_norm = rows
-                n = R * D
-                ops.adamw_rows_l2norm(f.master[:n].view(R, D), f.grad[:n].view(R, D), mv[0][:n].view(R, D), mv[1][:n].view(R, D),
-                                      w_hat, inv_norm, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._t,
-                                      self.grad_scale, dev_hyper=self.dev_hyper)
-                rn.mark_normalised()
-                continue
-            ops.adamw_step(f.master, f.grad, mv[0], mv[1], f.shadow, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                           g["weight_decay"], self._t, self.grad_scale, dev_hyper=self.dev_hyper, shadow16=f.shadow16)
+            pos = 0
+            for lo, hi in sorted(done.get(id(f), [])) + [(f.total, f.total)]:
+                if lo > pos:
+                    self._update(f, pos, lo)
+                pos = max(pos, hi)
             f._shadow_version = f.master._version
-            if rn is not None:
-                rn.invalidate_normalised()          # the master changed under the module: its cached w_hat is stale
-        return None
+
+    # ---- the same step issued RANGE BY RANGE while the backward is still running (train.TrainStep, single process): the towers
+    # report gradient ranges as they become final (grad_ready_hook), each range's update is launched at once on the caller's
+    # optimiser stream, finish_ranged_step() does whatever was not reported.  Element for element the arithmetic of step().
+    @torch.no_grad()
+    def begin_ranged_step(self):
+        self._t += 1
+        self._done = {}
+
+    @torch.no_grad()
+    def step_range(self, f, lo, hi):
+        if f.grad is None or hi <= lo:
+            return
+        f.ensure_device_state()
+        self._update(f, lo, hi)
+        self._done.setdefault(id(f), []).append((lo, hi))
+
+    @torch.no_grad()
+    def finish_ranged_step(self):
+        done, self._done = self._done, None
+        self._finish(done)
 
     # ---- checkpointing (the reference saves optimiser dicts next to the model, cv_classifier_train_daodian.py:298-306)
     def state_dict(self):

@@ -159,6 +159,43 @@ class TrainStep:
         self.t = 0
         self._set_lr()
         self.ce = torch.nn.CrossEntropyLoss()
+        self._init_opt_in_backward()
+
+    # ---- the optimiser updates issued DURING the backward (single process; MMSIM_OPT_IN_BWD=1 turns it on, default OFF).  AdamW is a
+    # pure HBM stream (3.4 ms per step at cfg4 with the matrix pipes idle) and the text tower's backward a chain of MFMA-bound products
+    # that leave HBM idle: the head's update (its gradient is final before the towers' backward starts) and each encoder layer's
+    # range run on their own stream beside those products.  Same launches on the same data -- bit-identical to stepping at the end
+    # (tests/test_gpu_graph_step.py).  MEASURED (round 4, cfg4, alternating runs on one box): 98.2 / 98.2 ms per step against
+    # 92.3 / 92.1 with the updates at the end -- 6 ms SLOWER.  The AdamW grids (8 192 short blocks, 60-90 registers, 8 waves per SIMD)
+    # fill every CU's register file between two rounds of a pipelined GEMM, whose 512-thread / 160-KiB workgroups then wait for
+    # whole CUs to drain; the products lose far more than the 3.4 ms the update is worth.  Kept as a switch for configurations
+    # whose backward is not wall-to-wall full-chip products.
+    def _init_opt_in_backward(self):
+        self._oib = None
+        dev_ok = any(f.master.is_cuda for f in self.opt_emb.flats)
+        if self.exchange is not None or not dev_ok or os.environ.get("MMSIM_OPT_IN_BWD", "0") != "1":
+            return
+        from .bert import BertModel
+        from .head import ArcMarginProduct
+        owner = {id(f): self.opt_emb for f in self.opt_emb.flats}
+        owner.update({id(f): self.opt_fc for f in self.opt_fc.flats})
+        mods = [m for m in self.model.modules() if isinstance(m, (BertModel, ArcMarginProduct)) and hasattr(m, "grad_ready_hook")
+                and all(id(f) in owner for f in m.flat_buffers())]
+        if not mods:
+            return
+        self._oib = dict(owner=owner, stream=torch.cuda.Stream(), active=False)
+        for m in mods:
+            m.grad_ready_hook = self._on_grad_ready
+
+    def _on_grad_ready(self, flat, lo, hi):
+        o = self._oib
+        if not o["active"]:
+            return
+        ev = torch.cuda.Event()
+        ev.record()                               # behind every kernel of the reporting tower that reads or writes this range
+        o["stream"].wait_event(ev)
+        with torch.cuda.stream(o["stream"]):
+            o["owner"][id(flat)].step_range(flat, lo, hi)
 
     def _set_lr(self):
         self.opt_emb.param_groups[0]["lr"] = linear_schedule_lr(self.lr_emb0, self.t, 0, self.total)
@@ -175,14 +212,27 @@ class TrainStep:
             logits = model(**kw)
             loss = self.ce(logits, batch["labels"])
             pred = torch.argmax(logits, dim=-1)
-        loss.backward()
+        if self._oib:
+            self.opt_emb.begin_ranged_step(); self.opt_fc.begin_ranged_step()
+            self._oib["active"] = True
+        try:
+            loss.backward()
+        finally:
+            if self._oib:
+                self._oib["active"] = False
         if self.exchange:
             self.exchange.finish()
         # reference order (multimodal_classifier_train.py:195-201): BOTH optimisers step with lr(t); each schedule
         # advances right after its own optimiser, so the head's first warm-up step runs at lr 0 and the last step at lr(T-1)
-        self.opt_emb.step()
-        self.opt_emb.zero_grad()
-        self.opt_fc.step()
+        if self._oib:
+            torch.cuda.current_stream().wait_stream(self._oib["stream"])     # the ranged updates are part of this step
+            self.opt_emb.finish_ranged_step()
+            self.opt_emb.zero_grad()
+            self.opt_fc.finish_ranged_step()
+        else:
+            self.opt_emb.step()
+            self.opt_emb.zero_grad()
+            self.opt_fc.step()
         self.opt_fc.zero_grad(lazy=True)        # the head's dW product overwrites its whole buffer next step (flat.zero_grad)
         return loss.detach(), pred
 

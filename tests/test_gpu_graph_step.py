@@ -111,3 +111,28 @@ def test_capture_starts_from_a_canonical_gradient_state(deterministic):
     finally:
         g.close()
     assert max(abs(a - b) for a, b in zip(got, eager)) < 1e-5 * abs(eager[0]), (got, eager)
+
+
+def test_optimiser_updates_issued_during_the_backward_are_bit_identical(deterministic, monkeypatch):
+    """MMSIM_OPT_IN_BWD=1: the head's and each encoder layer's AdamW range launched from the towers' grad_ready hooks on a side
+    stream (optim.FusedAdamW.step_range) against the two updates at the end of the step -- same kernels on the same data, so the
+    losses and every parameter are bit-identical; every element is updated exactly once (the unreported ranges at the end)."""
+    from multimodalsimilar_amd import train as T
+    cfg = dict(T.CONFIGS["tiny"])
+    batches = [T.synthetic_batch(cfg, "cuda", seed=70 + i) for i in range(4)]
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MMSIM_OPT_IN_BWD", flag)
+        m = _model(cfg, False)
+        ts = T.TrainStep(m, cfg["kind"], 10)
+        assert (ts._oib is not None) == (flag == "1")
+        losses = [ts.step(b)[0].item() for b in batches]
+        torch.cuda.synchronize()
+        out.append((losses, {k: v.clone() for k, v in m.state_dict().items()}))
+        if flag == "1":
+            done = ts.opt_emb._done
+            assert done is None                     # finish_ranged_step consumed the ranges
+    (l0, sd0), (l1, sd1) = out
+    assert l0 == l1, (l0, l1)
+    diff = [k for k in sd0 if not torch.equal(sd0[k], sd1[k])]
+    assert not diff, diff[:6]
