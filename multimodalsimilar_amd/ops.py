@@ -234,7 +234,9 @@ def pick_split_k(M, N, K):
     # splits = 40 MB of atomics for a 1.8 MB gradient; halving the splits took the 20 late-stage blocks from 5.08 to 4.85 ms)
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     s = 1
-    target = int(os.environ.get("MMSIM_SPLITK_TARGET", "192"))
+    # (outputs the pipelined 256x128 kernel takes -- M a multiple of 256, N of 128 -- keep its ~512 blocks: the text tower's
+    # attention-output weight gradient on its own measured 720 TFLOP/s at 8 splits and 502 at 4)
+    target = 512 if (M % 256 == 0 and N % 128 == 0) else int(os.environ.get("MMSIM_SPLITK_TARGET", "192"))
     while tiles * s < target and K // (s * 2) >= 512:
         s *= 2
     return s * mult

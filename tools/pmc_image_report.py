@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 from multimodalsimilar_amd.effnet import build_arch
 B = 256
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
-ONE_STREAM = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", {"r03": "r03_b", "r04": "r04_a"}.get(TAG, TAG) + "_bench_cfg4_kernel_stats_one_stream.csv")
+ONE_STREAM = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", {"r03": "r03_b", "r04": "r04_c"}.get(TAG, TAG) + "_bench_cfg4_kernel_stats_one_stream.csv")
 a = build_arch("efficientnet_b4")
 h = 112
 fam = {}
@@ -23,12 +23,15 @@ for b in a.blocks:
     plain = b.type == "ds"
     if b.stride == 1 and b.k == 5 and not plain and TAG >= "r04":      # round 4: the 5 x 5 blocks on the matrix cores (backward from 14^2 up)
         add("dwm_fwd_kernel<5, true, false>", 2 * e_in, 2 * e_out)
-        add("dwm_bwd_kernel<5>" if ho >= 14 else "dwt_bwd_kernel<5, false>", 2 * 3 * e_out, 2 * e_in)
+        add("dwm_bwd_kernel<5>" if ho >= 14 else "dwt_bwd_kernel<5, false, 1>", 2 * 3 * e_out, 2 * e_in)
     elif b.stride == 1:
         add(f"dwt_fwd_kernel<{b.k}, 1, {'false' if plain else 'true'}>", 2 * e_in, 2 * e_out)                       # z1 (or x) -> z2
-        add(f"dwt_bwd_kernel<{b.k}, {'true' if plain else 'false'}>", 2 * 3 * e_out + (2 * e_out if plain and b.skip else 0), 2 * e_in)   # dy, z2, z1 -> dpre1
+        add(f"dwt_bwd_kernel<{b.k}, {'true' if plain else 'false'}, 1>", 2 * 3 * e_out + (2 * e_out if plain and b.skip else 0), 2 * e_in)   # dy, z2, z1 -> dpre1
     else:
         add(f"dwt_fwd_kernel<{b.k}, 2, true>", 2 * e_in, 2 * e_out)
+        add(f"dwt_bwd_kernel<{b.k}, false, 2>", 2 * (2 * e_out + e_in), 2 * e_in)                                      # dy, z2 (output plane), z1 -> dpre1 (input plane)
+    if not plain and not (b.mid <= 352 and b.cin <= 64):      # expand BatchNorm's backward as its own pass (where mmsim_pw_expand_bwd is not eligible)
+        add("bn_bwd_apply_kernel", 2 * 2 * e_in, 2 * e_in)
     add("pool_bn_bwd_kernel", 2 * 2 * e_out, 0)                                                                        # z2, da2g -> [5][B][C] sums
     add("pool_bn_act_kernel", 2 * e_out, 0 if ho > 28 or (ho == 28 and b.mid <= 192) else 2 * e_out)                 # z2 -> squeeze (+ a2 where it is kept)
     add("bn_bwd_apply_kernel", 2 * 2 * B * ho * ho * b.cout, 2 * B * ho * ho * b.cout)                                # bn3: dy, z3 -> dz3
