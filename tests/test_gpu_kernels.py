@@ -99,6 +99,27 @@ def test_gemm_epilogues_and_splitk():
     assert relerr(out, base + pre - bias) < 2e-3
 
 
+@pytest.mark.parametrize("layout", ["nt", "nn"])
+@pytest.mark.parametrize("M,N,K,sk", [(200, 136, 1024, 4), (513, 264, 1096, 3), (128, 128, 96, 1), (1000, 40, 224, 2)])
+def test_generic_ring_gemm_ragged_edges_and_splitk(M, N, K, sk, layout):
+    """The LDS-DMA ring form of the generic 128 x 128 product (gemm_ring_kernel: forward and data-gradient layouts, K >= 96 per split):
+    ragged M / N (rows re-read, outputs predicated), K tails of 8 / 16 elements (zero chunks as DMA source), split-K atomics on top of
+    existing contents -- against fp32 torch."""
+    ops = _ops()
+    a = rnd(M, K, seed=11).bfloat16()
+    b = rnd(N, K, seed=12, scale=0.1).bfloat16()
+    ref = a.float() @ b.float().t()
+    Bm, kw = (b, dict()) if layout == "nt" else (b.t().contiguous(), dict(b_kmajor=False))
+    base = rnd(M, N, seed=13)
+    out = base.clone()
+    ops.gemm(a, Bm, out, split_k=sk, accumulate=True, **kw)
+    assert relerr(out, base + ref) < 2e-3
+    cb = ops.alloc_2d(M, N, torch.bfloat16, DEV)
+    r = rnd(M, N, seed=14).bfloat16()
+    ops.gemm(a, Bm, cb, epilogue=ops.EPI_ADD, aux_in=r, **kw)
+    assert relerr(cb, ref + r.float()) < 1e-2
+
+
 def test_gemm_rejects_bad_arguments():
     ops = _ops()
     from multimodalsimilar_amd import MmsimError
