@@ -165,21 +165,24 @@ class TrainStep:
     # pure HBM stream (3.4 ms per step at cfg4 with the matrix pipes idle) and the text tower's backward a chain of MFMA-bound products
     # that leave HBM idle: the head's update (its gradient is final before the towers' backward starts) and each encoder layer's
     # range run on their own stream beside those products.  Same launches on the same data -- bit-identical to stepping at the end
-    # (tests/test_gpu_graph_step.py).  MEASURED (round 4, cfg4, alternating runs on one box): 98.2 / 98.2 ms per step against
-    # 92.3 / 92.1 with the updates at the end -- 6 ms SLOWER.  The AdamW grids (8 192 short blocks, 60-90 registers, 8 waves per SIMD)
-    # fill every CU's register file between two rounds of a pipelined GEMM, whose 512-thread / 160-KiB workgroups then wait for
-    # whole CUs to drain; the products lose far more than the 3.4 ms the update is worth.  Kept as a switch for configurations
-    # whose backward is not wall-to-wall full-chip products.
+    # (tests/test_gpu_graph_step.py).  MEASURED (round 4, cfg4, alternating runs on one box).  Replayed hipGraph: 98.2 / 98.2 ms per
+    # step against 92.3 / 92.1 with the updates at the end -- 6 ms SLOWER; with the towers' ranges only ("2", no head update) 98.9
+    # against 93.2, and capping the update's grid at 256 / 1 024 blocks (one wave per SIMD, which fits beside a GEMM workgroup) changes
+    # nothing (98.4 / 98.7).  EAGER launches of the same step: 93.3 against 93.7 -- a small gain, the size the co-residency
+    # experiment predicts (a third of the 1.9 ms moved).  So the loss is the replayed graph's: with ~26 more fork / join edges per step
+    # its branches are no longer scheduled as two long streams.  Off; kept for eager (data-parallel) runs to try.
     def _init_opt_in_backward(self):
         self._oib = None
         dev_ok = any(f.master.is_cuda for f in self.opt_emb.flats)
-        if self.exchange is not None or not dev_ok or os.environ.get("MMSIM_OPT_IN_BWD", "0") != "1":
+        mode = os.environ.get("MMSIM_OPT_IN_BWD", "0")
+        if self.exchange is not None or not dev_ok or mode not in ("1", "2"):
             return
         from .bert import BertModel
         from .head import ArcMarginProduct
         owner = {id(f): self.opt_emb for f in self.opt_emb.flats}
         owner.update({id(f): self.opt_fc for f in self.opt_fc.flats})
-        mods = [m for m in self.model.modules() if isinstance(m, (BertModel, ArcMarginProduct)) and hasattr(m, "grad_ready_hook")
+        kinds = (BertModel, ArcMarginProduct) if mode == "1" else (BertModel,)        # "2": the towers' ranges only
+        mods = [m for m in self.model.modules() if isinstance(m, kinds) and hasattr(m, "grad_ready_hook")
                 and all(id(f) in owner for f in m.flat_buffers())]
         if not mods:
             return
