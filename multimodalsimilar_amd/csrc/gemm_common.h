@@ -55,6 +55,31 @@ __device__ __forceinline__ void gelu_both_f(float x, float& g, float& dg) {
   dg = cdf + x * (0.39894228040143268f * E);
 }
 
+// Two elements at a time on the packed fp32 pipes (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: one issue slot for two lanes' worth of
+// arithmetic): the polynomial, the products and the final combinations are 2-wide, only |x|, the two transcendentals and the sign select
+// stay per element.  The GELU-pair epilogue is VALU work with the matrix pipes idle (~25 instructions per element on 134 M elements per
+// launch), so issue slots are what it costs.
+#ifndef GELU_PK
+#define GELU_PK 1
+#endif
+typedef float __attribute__((ext_vector_type(2))) f2v;
+__device__ __forceinline__ void gelu_both_pk(f2v x, f2v& g, f2v& dg) {
+  const f2v ax = {fabsf(x[0]), fabsf(x[1])};
+  const f2v xx = x * x * -0.5f;
+  const f2v E = {__expf(xx[0]), __expf(xx[1])};
+  const f2v den = ax * (0.3275911f * 0.70710678118654752f) + 1.0f;
+  const f2v t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f2v poly = t * 1.061405429f + -1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t + -0.284496736f;
+  poly = poly * t + 0.254829592f;
+  poly = poly * t;
+  const f2v q = poly * E * 0.5f;                      // 1 - Phi(|x|)
+  const f2v cdf = {x[0] >= 0.f ? 1.0f - q[0] : q[0], x[1] >= 0.f ? 1.0f - q[1] : q[1]};
+  g = x * cdf;
+  dg = x * (E * 0.39894228040143268f) + cdf;
+}
+
 // Epilogue for full tiles, staged through LDS so that every global access is row-contiguous: the wave's 64x64
 // fp32 tile is written to its private LDS region (the operand ring is free by then) and read back one row segment
 // per 16 lanes: 128-B bf16 / 256-B fp32 stores and aux loads (whole cache lines), and for split-K one 256-B
@@ -306,8 +331,17 @@ __device__ __forceinline__ void fast_epilogue_bf16_wide(const GemmParams& p, f4 
     for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
     if (EPI == EPI_GELU_DGELU) {
       bf8 dg;
+#if !GELU_PK      // A/B builds only (tools/build_variant.sh -DGELU_PK=0): the element-at-a-time form
 #pragma unroll
       for (int e = 0; e < 8; ++e) { float g, d; gelu_both_f(bf2f(f2bf(v[e])), g, d); v[e] = g; dg[e] = f2bf(d); }
+#else
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        f2v g, d;
+        gelu_both_pk((f2v){bf2f(f2bf(v[e])), bf2f(f2bf(v[e + 1]))}, g, d);
+        v[e] = g[0]; v[e + 1] = g[1]; dg[e] = f2bf(d[0]); dg[e + 1] = f2bf(d[1]);
+      }
+#endif
       __builtin_nontemporal_store(dg, reinterpret_cast<bf8*>(p.aux_out + m * p.ld_aux + n));
     } else if (EPI == EPI_GELU) {
       bf8 pre;
