@@ -65,16 +65,15 @@ __device__ __forceinline__ void gelu_both_f(float x, float& g, float& dg) {
 typedef float __attribute__((ext_vector_type(2))) f2v;
 __device__ __forceinline__ void gelu_both_pk(f2v x, f2v& g, f2v& dg) {
   const f2v ax = {fabsf(x[0]), fabsf(x[1])};
-  const f2v xx = x * x * -0.5f;
-  const f2v E = {__expf(xx[0]), __expf(xx[1])};
+  const f2v xx = x * x * (-0.5f * 1.4426950408889634f);                  // exp(-x^2 / 2) = exp2(-x^2 / 2 * log2 e): no separate scaling multiply
+  const f2v E = {__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};
   const f2v den = ax * (0.3275911f * 0.70710678118654752f) + 1.0f;
   const f2v t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
   f2v poly = t * 1.061405429f + -1.453152027f;
   poly = poly * t + 1.421413741f;
   poly = poly * t + -0.284496736f;
   poly = poly * t + 0.254829592f;
-  poly = poly * t;
-  const f2v q = poly * E * 0.5f;                      // 1 - Phi(|x|)
+  const f2v q = poly * t * E * 0.5f;                                      // 1 - Phi(|x|)
   const f2v cdf = {x[0] >= 0.f ? 1.0f - q[0] : q[0], x[1] >= 0.f ? 1.0f - q[1] : q[1]};
   g = x * cdf;
   dg = x * (E * 0.39894228040143268f) + cdf;
@@ -338,7 +337,7 @@ __device__ __forceinline__ void fast_epilogue_bf16_wide(const GemmParams& p, f4 
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
         f2v g, d;
-        gelu_both_pk((f2v){bf2f(f2bf(v[e])), bf2f(f2bf(v[e + 1]))}, g, d);
+        gelu_both_pk((f2v){v[e], v[e + 1]}, g, d);      // of the fp32 pre-activation (gelu and gelu' from the same value; no bf16 round trip)
         v[e] = g[0]; v[e + 1] = g[1]; dg[e] = f2bf(d[0]); dg[e + 1] = f2bf(d[1]);
       }
 #endif
